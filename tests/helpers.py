@@ -1,0 +1,55 @@
+"""Shared fixture loading for the parity tests (test infrastructure; may import the oracle)."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ptg_oracle as po  # noqa: E402
+
+TRAJ_CASES = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLD, "traj_*.npz")))
+PREP_CASES = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLD, "prep_*.npz")))
+
+_cache = {}
+
+
+def load_npz(path):
+    if path not in _cache:
+        z = np.load(path, allow_pickle=False)
+        d = {k: z[k] for k in z.files}
+        if "meta" in d:
+            d["meta"] = json.loads(str(d["meta"]))
+        _cache[path] = d
+    return _cache[path]
+
+
+def load_tables(op):
+    z = load_npz(os.path.join(ROOT, "rl_ptg_amd", "data", f"tables_{op}.npz"))
+    return {k: z[k] for k in po.TABLE_KEYS}
+
+
+def load_prep(name):
+    return load_npz(os.path.join(GOLD, f"prep_{name}.npz"))
+
+
+def load_traj(case):
+    """-> (traj dict, consts, tables, market) with market series taken from the referenced prep fixture."""
+    tr = load_npz(os.path.join(GOLD, f"traj_{case}.npz"))
+    meta = tr["meta"]
+    prep = load_prep(meta["prep"])
+    sp = meta["split"]
+    market = dict(el=prep[f"el_{sp}"], pot_rew=prep[f"pot_rew_{sp}"], part_full=prep[f"part_full_{sp}"].astype(np.float64),
+                  gas=prep[f"gas_{sp}"], eua=prep[f"eua_{sp}"],
+                  eps_ind=tr["eps_ind"] if len(tr["eps_ind"]) else None)
+    return tr, dict(meta["consts"]), load_tables(meta["operation"]), market
+
+
+def make_oracle(case):
+    tr, consts, tables, market = load_traj(case)
+    env = po.OracleVecEnv(consts, tables, market, tr["meta"]["n_envs"], ep_index0=tr["meta"]["ep_index0"])
+    env.set_noise_tape(tr["noise"])
+    return tr, env
