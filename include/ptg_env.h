@@ -1,0 +1,174 @@
+/*
+ * ptg_env.h -- C ABI of the MI355X-native batched Power-to-Gas environment (libptg_env.so).
+ *
+ * Drop-in boundary for the reference's hot path: N independent copies of
+ *     PTGEnv.step / PTGEnv.reset            /root/reference/env/ptg_gym_env.py:336-481, :483-506
+ * as the reference vectorises them with SB3's DummyVecEnv (src/rl_utils.py:448-453, :484): envs are stepped
+ * in env order and a finished env is reset at once.  The Python side (rl_ptg_amd/vec_env.py) binds these
+ * entry points with ctypes and presents the VecEnv / gym.Env surface; INTEGRATION.md shows the reference-side
+ * binding.  Plain C types only: no torch / numpy types cross this boundary.
+ *
+ * Pointer conventions
+ *   *_host : host memory, read (or written) synchronously during the call.
+ *   *_dev  : device memory on the handle's GPU (e.g. torch.Tensor.data_ptr() of a ROCm tensor), accessed
+ *            asynchronously on the hipStream_t passed as `stream` (NULL = the default stream).
+ * Ownership: the caller owns every buffer it passes; the library owns its device-resident state, tables and
+ * price series (copies made in ptg_create) until ptg_destroy.
+ * Errors: every function returns 0 on success or a negative PTG_E_* code; ptg_last_error() gives the text.
+ * No C++ exception crosses the boundary.  A handle is not thread-safe; work is stream-ordered.
+ */
+#ifndef PTG_ENV_H
+#define PTG_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTG_ABI_VERSION 1
+#define PTG_N_TABLES 17
+#define PTG_N_COLS 7
+#define PTG_N_INFO 24
+#define PTG_MAX_MARKET_SETS 4
+
+enum {
+    PTG_OK = 0,
+    PTG_E_INVALID = -1,        /* bad argument / call order */
+    PTG_E_HIP = -2,            /* a HIP runtime call failed (no device, out of memory, ...) */
+    PTG_E_ACTION = -3,         /* a discrete action outside [-5, 4] reached a kernel (reference: IndexError, :347) */
+    PTG_E_RANGE = -4           /* a price index left the series (reference: IndexError, :446-447) */
+};
+
+/* table ids: order of op_data_files, src/rl_utils.py:108-113 */
+enum {
+    PTG_T_STARTUP_COLD = 0, PTG_T_STARTUP_HOT, PTG_T_COOLDOWN, PTG_T_STANDBY_DOWN, PTG_T_STANDBY_UP,
+    PTG_T_OP1_START_P, PTG_T_OP2_START_F, PTG_T_OP3_P_F, PTG_T_OP4_P_F_P_5, PTG_T_OP5_P_F_P_10,
+    PTG_T_OP6_P_F_P_15, PTG_T_OP7_P_F_P_22, PTG_T_OP8_F_P, PTG_T_OP9_F_P_F_5, PTG_T_OP10_F_P_F_10,
+    PTG_T_OP11_F_P_F_15, PTG_T_OP12_F_P_F_20
+};
+
+enum { PTG_ACT_I32 = 0, PTG_ACT_F32 = 1, PTG_ACT_I64 = 2 };   /* element type of the action buffer */
+enum { PTG_OUT_F32 = 0, PTG_OUT_F64 = 1 };                    /* element type of obs / reward buffers */
+
+/* Constants of the env: the flat kwargs of Preprocessing.dict_env_kwargs (src/rl_utils.py:345-365), same names.
+ * Replaces: the attribute set PTGEnv.__init__ copies from dict_input (env/ptg_gym_env.py:40). */
+typedef struct ptg_config {
+    double noise;                       /* config_env.yaml:28; informational for host tapes, sigma of ptg_fill_noise_tape */
+    int32_t eps_len_d, sim_step, time_step_op, price_ahead;
+    double convert_mol_to_Nm3, H_u_CH4, H_u_H2, dt_water, cp_water, rho_water, Molar_mass_CO2,
+           Molar_mass_H2O, h_H2O_evap, eeg_el_price, heat_price, o2_price, water_price,
+           min_load_electrolyzer, max_h2_volumeflow, eta_CHP;
+    double t_cat_standby, t_cat_startup_cold, t_cat_startup_hot;
+    int32_t time1_start_p_f, time2_start_f_p, time_p_f, time_f_p, time1_p_f_p, time2_p_f_p, time23_p_f_p,
+            time3_p_f_p, time34_p_f_p, time4_p_f_p, time45_p_f_p, time5_p_f_p, time1_f_p_f, time2_f_p_f,
+            time23_f_p_f, time3_f_p_f, time34_f_p_f, time4_f_p_f, time45_f_p_f, time5_f_p_f,
+            i_fully_developed, j_fully_developed;
+    double el_l_b, el_u_b, gas_l_b, gas_u_b, eua_l_b, eua_u_b, T_l_b, T_u_b, h2_l_b, h2_u_b, ch4_l_b,
+           ch4_u_b, h2_res_l_b, h2_res_u_b, h2o_l_b, h2o_u_b, heat_l_b, heat_u_b;
+    int32_t raw_modified;               /* 0 = "raw" (26 features), 1 = "mod" (35 features); :165,185 */
+    int32_t action_type;                /* 0 = "discrete", 1 = "continuous"; :144-158 */
+    int32_t train_or_eval;              /* 0 = "train", 1 = "eval" (info rows available); :471-474 */
+    int32_t eps_sim_steps;              /* :508-511 */
+    double state_change_penalty;        /* :332 */
+    double t_cat_initial;               /* 16 in the reference (:117) */
+    int32_t out_dtype;                  /* PTG_OUT_F32 | PTG_OUT_F64 */
+    int32_t reserved;
+} ptg_config;
+
+/* The 17 process tables (src/rl_utils.py:46-67): row-major [rows][7] = t, T_cat, n_h2, n_ch4, n_h2_res, m_h2o, P_el */
+typedef struct ptg_tables {
+    const double* data_host[PTG_N_TABLES];
+    int32_t rows[PTG_N_TABLES];
+} ptg_tables;
+
+/* One business scenario's market view as 1-D series.  Replaces the materialised tensors
+ *   e_r_b[c, i, t] == series_c[t + i]  (src/rl_utils.py:250-263)   g_e[c, i, d] == series_c[d + i]  (:266-281)
+ * plus the scenario-dependent scalars (b_s3 env/ptg_gym_env.py:76-77; rew_l_b/u_b src/rl_utils.py:378-379;
+ * r_0 = reward_level[0] env/ptg_gym_env.py:125).  All sets of one handle share n_hours / n_days. */
+typedef struct ptg_market {
+    int32_t n_hours;                    /* >= last hour index used + price_ahead */
+    const double* el_host;              /* ct/kWh */
+    const double* pot_rew_host;         /* ct/h   (calculate_optimum, src/rl_opt.py:26-152, column 20) */
+    const double* part_full_host;       /* -1/0/1 (column 23) */
+    int32_t n_days;
+    const double* gas_host;             /* ct/kWh, scenario override applied (src/rl_utils.py:119-126) */
+    const double* eua_host;             /* Euro/t */
+    int32_t scenario;                   /* 1, 2 or 3 */
+    int32_t reserved;
+    double rew_l_b, rew_u_b, r_0;
+} ptg_market;
+
+typedef struct ptg_env ptg_env;
+
+/* ---- life cycle ---------------------------------------------------------------------------------------- */
+/* Builds the device-resident tables for step_size = sim_step / time_step_op:
+ *   window records (row 12 of SURVEY §8a: T of the last row + NumPy-pairwise means of the 5 flow columns for every
+ *   possible window start, incl. the table-end / startup->partial splice cases of _perform_sim_step :525-557) and
+ *   the _get_index lookup (:514-523) for every distinct catalyst temperature x 6 destination tables.
+ * Replaces PTGEnv.__init__ (:28-79) for n_envs envs.  Envs must be reset before the first step. */
+int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market* sets, int n_sets,
+               int n_envs, int device_id, ptg_env** out);
+void ptg_destroy(ptg_env* env);
+int ptg_abi_version(void);
+int ptg_num_envs(const ptg_env* env);
+int ptg_obs_dim(const ptg_env* env);                 /* 35 ('mod') / 26 ('raw') for price_ahead = 13 */
+const char* ptg_last_error(const ptg_env* env);      /* env may be NULL: error of the last failed ptg_create */
+
+/* ---- configuration of the batch ------------------------------------------------------------------------ */
+/* market set (business scenario) of every env; default 0 */
+int ptg_set_market_assignment(ptg_env* env, const uint8_t* set_of_env_host);
+/* Training episodes (env/ptg_gym_env.py:59-62, :490-493): eps_ind as the reference holds it.  Env e takes
+ * eps_ind[(first_ptr + e + m*stride) mod n] at its m-th reset from now on: with first_ptr = N_total + shard_offset and
+ * stride = N_total this is the order in which N_total reference envs sharing the module-global ep_index reset under
+ * DummyVecEnv when they terminate together (exclusive prefix sum over done flags).  n = 0: validation/test env. */
+int ptg_set_episode_plan(ptg_env* env, const double* eps_ind_host, int n, int64_t first_ptr, int64_t stride);
+/* Normal draws consumed at state changes (:584-585,598-599,620-621): the c-th draw of env e is tape[e*len + c mod len].
+ * Host tape (e.g. numpy Generator.normal(0, noise) per env for bit parity with the reference) ... */
+int ptg_set_noise_tape(ptg_env* env, const double* tape_host, int per_env_len);
+/* ... or filled on the device: Philox4x32-10 keyed by (seed, epoch) + Box-Muller, sigma = cfg.noise. Resets the counters. */
+int ptg_fill_noise_tape(ptg_env* env, uint64_t seed, int per_env_len, void* stream);
+int ptg_get_noise_tape(ptg_env* env, double* tape_host);          /* [n_envs][per_env_len] */
+
+/* ---- the hot path --------------------------------------------------------------------------------------- */
+/* reset (:483-506) of all envs (mask_host NULL) or of those with mask != 0; obs rows of reset envs are written. */
+int ptg_reset(ptg_env* env, const uint8_t* mask_host, void* obs_dev, void* stream);
+/* One vector step (:336-481) + DummyVecEnv auto-reset.
+ *   actions_dev  [N]     int32 / float32 / int64 per action_kind (PTG_ACT_*)
+ *   obs_dev      [N][F]  out_dtype; row of a finished env = observation after its reset
+ *   rew_dev      [N]     out_dtype
+ *   done_dev     [N]     uint8
+ *   final_obs_dev[N][F]  (nullable) rows of finished envs = terminal observation
+ *   info_dev     [N][24] (nullable, float64) _get_info (:251-278) in key order, Meth_Action as its index */
+int ptg_step(ptg_env* env, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev,
+             uint8_t* done_dev, void* final_obs_dev, double* info_dev, void* stream);
+/* T vector steps in one launch, state held in registers: actions [T][N] -> obs [T][N][F], rew [T][N], done [T][N].
+ * Same results as T calls of ptg_step. */
+int ptg_rollout(ptg_env* env, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
+                uint8_t* done_dev, void* stream);
+/* hipStreamSynchronize(stream) + report an error a kernel flagged (PTG_E_ACTION / PTG_E_RANGE). */
+int ptg_sync(ptg_env* env, void* stream);
+
+/* ---- state access (parity tests, checkpointing) -------------------------------------------------------- */
+enum {
+    PTG_F_METH_STATE = 0, PTG_F_I, PTG_F_J, PTG_F_K, PTG_F_HOT_COLD, PTG_F_STANDBY_TID, PTG_F_STARTUP_TID,
+    PTG_F_PARTIAL_TID, PTG_F_FULL_TID, PTG_F_CURRENT_ACTION, PTG_F_ACT_EP_D, PTG_F_EP_PTR, PTG_F_NOISE_COUNT,
+    PTG_F_N_STATE_CHANGES, PTG_F_MARKET_SET,       /* int32[N] */
+    PTG_F_T_CAT = 32, PTG_F_CUM_REW                /* float64[N] */
+};
+int ptg_get_state(ptg_env* env, int field, void* out_host);
+int ptg_set_state(ptg_env* env, int field, const void* in_host);
+
+/* Episodes finished since the last call (Monitor's info["episode"]: r = sum of returned rewards, l = steps),
+ * compacted on the device with a wave ballot prefix.  Returns up to cap entries and clears the list. */
+int ptg_finished_episodes(ptg_env* env, double* returns_host, int32_t* lengths_host, int32_t* env_ids_host,
+                          int cap, int* count);
+
+/* diagnostics for tests: the device-built lookup products */
+int ptg_debug_get_index_lut(ptg_env* env, double* T_values_host, int32_t* lut_host /*[6][nT]*/, int* n_T);
+int ptg_debug_window_record(ptg_env* env, int table_id, int start_row, double* out7_host /*T_last, 5 means, key*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTG_ENV_H */

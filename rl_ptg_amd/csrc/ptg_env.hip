@@ -1,0 +1,1207 @@
+// ptg_env.hip -- MI355X (gfx950) implementation of include/ptg_env.h: HIP kernels + C ABI.
+//
+// What replaces what (reference = /root/reference/env/ptg_gym_env.py):
+//   k_build_records   _perform_sim_step's window (:525-557) + the five np.average reductions and the last-row
+//                     catalyst temperature (:452-458), evaluated ONCE for every possible window start of every
+//                     table, with NumPy's pairwise summation order -> one 64-byte record per start row.
+//   k_build_argmin    _get_index (:514-523) for every distinct catalyst temperature x 6 destination tables.
+//   k_step / k_rollout  step() (:336-481) + DummyVecEnv auto-reset (reset :483-506) over a struct-of-arrays of N envs:
+//                     one lane per env, integer state machine (:339-440), one record gather, reward (:280-334),
+//                     normalisation (:206-217), observation row (:219-249), info row (:251-278).
+//   k_reset           reset() (:483-506).
+//   k_fill_noise      the normal(0, noise) draws of :585/:599/:621 as a counter-based device RNG (Philox4x32-10).
+// Built with -ffp-contract=off: the float64 expressions keep the reference's operand order.
+#include "../../include/ptg_env.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int NT = PTG_N_TABLES;
+constexpr int NC = PTG_N_COLS;
+constexpr int N_DEST = 6;   // destination tables of _get_index: cooldown, standby_up, standby_down, startup_cold, startup_hot, op1_start_p
+constexpr int DEST_TID[N_DEST] = {PTG_T_COOLDOWN, PTG_T_STANDBY_UP, PTG_T_STANDBY_DOWN, PTG_T_STARTUP_COLD,
+                                  PTG_T_STARTUP_HOT, PTG_T_OP1_START_P};
+
+// ------------------------------------------------------------------------------------------------ device data
+struct alignas(64) Rec {      // one window start: 64 B = half an L2 line, never straddles a line
+    double T;                 // catalyst temperature of the window's last row (:452)
+    double m[5];              // np.average of n_h2, n_ch4, n_h2_res, m_h2o, P_el over the window (:454-458)
+    int tkey;                 // index of T in the sorted distinct-temperature list
+    int pad;
+    double spare;
+};
+static_assert(sizeof(Rec) == 64, "Rec must be 64 bytes");
+
+struct Regs {                 // per-env mutable state, as held in registers
+    int i, j, k;
+    unsigned flags;           // [0:3) meth_state [3] hot_cold [4] standby=up [5] startup=hot [6:9) part_op [9:12) full_op
+                              // [12:15) current_action [15:17) market set [17:32) T key
+    int act_d;                // act_ep_d (:61,492); act_ep_h = 24 * act_d
+    int nctr, nchg, epp;      // noise draws consumed, state changes this episode, pointer into eps_ind
+    double cum;               // cum_rew (:330)
+};
+
+struct DevParams {
+    int N, S, sim_step, eps_sim_steps, PA, F, mod, eps_len_d;
+    int E, ep_stride;                      // eps_ind length (0 = eval env), pointer stride (mod E)
+    int key_cold_max, key_hot_min, key_standby_max, key_init, i_reset, nT, tape_len;
+    int n_hours, n_days, hstride, dstride;
+    int t1_start_p_f, t2_start_f_p, t_p_f, t_f_p, t1_p_f_p, t2_p_f_p, t3_p_f_p, t34_p_f_p, t4_p_f_p, t45_p_f_p,
+        t5_p_f_p, t1_f_p_f, t2_f_p_f, t23_f_p_f, t3_f_p_f, t34_f_p_f, t4_f_p_f, t45_f_p_f, t5_f_p_f, i_full, j_full;
+    // reward / normalisation constants (:280-334, :206-217)
+    double c_mol, Hu_ch4, Hu_h2, dt_cp_evap, heat_price, o2_price, eeg, eta_chp, one_m_eta_chp, M_co2, M_h2o,
+           rho, water_price, min_load, max_h2, c_m2, c_m3, sim_step_d;
+    double T_lo, T_rng, h2_lo, h2_rng, ch4_lo, ch4_rng, h2r_lo, h2r_rng, h2o_lo, h2o_rng, heat_lo, heat_rng;
+    double reset_flow[5], T_init;
+    // tables
+    const Rec* rec;
+    const int2* tabmeta;                   // [17] {rows, record base}
+    const int* argidx;                     // [6][nT]
+    const double* Tvals;                   // [nT]
+    const double* tape;                    // [N][tape_len]
+    const int* eps_ind;                    // [E]
+    const double2* sincos;                 // [eps_sim_steps + 1]
+    // market, [set][...] with strides hstride / dstride
+    const double *el, *featA, *featB, *gas, *eua, *gas_n, *eua_n;
+    const double *pot_raw, *pf_raw;        // un-normalised pot_rew / part_full for info rows
+    const double2* setc;                   // [sets] {b_s3, r_0 * state_change_penalty}
+    // state (SoA)
+    int *st_i, *st_j, *st_k, *st_actd, *st_nctr, *st_nchg, *st_epp;
+    unsigned* st_flags;
+    double* st_cum;
+    // finished-episode list
+    double* fin_ret; int* fin_len; int* fin_env; int* fin_count; int fin_cap;
+    int* err;
+};
+
+__device__ __forceinline__ int part_tid(int p) { return p == 0 ? PTG_T_OP1_START_P : 7 + p; }          // 5, 8..12
+__device__ __forceinline__ int full_tid(int q) { return q == 0 ? PTG_T_OP2_START_F : (q == 1 ? PTG_T_OP3_P_F : 11 + q); }  // 6,7,13..16
+
+// ------------------------------------------------------------------------------------------------ table builders
+struct WinSrc {               // the S-row window _perform_sim_step would hand to step(), read in place
+    const double* tab;        // this table's rows
+    const double* nxt;        // op1_start_p rows (startup tables splice into it, :547-550)
+    int n, r, S;
+    bool splice, all_last;
+    __device__ double at(int q, int col) const {
+        if (all_last) return tab[(size_t)(n - 1) * NC + col];
+        int v = r + q;
+        if (v < n) return tab[(size_t)v * NC + col];
+        return splice ? nxt[(size_t)(v - n) * NC + col] : tab[(size_t)(n - 1) * NC + col];
+    }
+};
+
+// NumPy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src): blocks of <=128 with 8 accumulators.
+__device__ double pairwise_sum(const WinSrc& w, int col, int off, int n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int q = 0; q < n; q++) res += w.at(off + q, col);
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        for (int q = 0; q < 8; q++) r[q] = w.at(off + q, col);
+        int q8 = 8;
+        for (; q8 < n - (n % 8); q8 += 8)
+            for (int q = 0; q < 8; q++) r[q] += w.at(off + q8 + q, col);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; q8 < n; q8++) res += w.at(off + q8, col);
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sum(w, col, off, n2) + pairwise_sum(w, col, off + n2, n - n2);
+    }
+}
+
+__global__ void k_build_records(const double* __restrict__ tab, const int* __restrict__ rowkey, int n,
+                                const double* __restrict__ nxt, const int* __restrict__ nxtkey, int splice, int S,
+                                Rec* __restrict__ out)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    WinSrc w{tab, nxt, n, r, S, splice != 0, r == n};
+    Rec rec;
+    for (int c = 0; c < 5; c++) {
+        double s = 0.0 + pairwise_sum(w, 2 + c, 0, S);
+        rec.m[c] = s / (double)S;
+    }
+    rec.T = w.at(S - 1, 1);
+    int last = r + S - 1;
+    rec.tkey = (r == n || last < n) ? rowkey[min(last, n - 1)] : (splice ? nxtkey[last - n] : rowkey[n - 1]);
+    rec.pad = 0;
+    rec.spare = 0.0;
+    out[r] = rec;
+}
+
+// first index of min |T_r - Tq|  (ndarray.argmin keeps the first minimum)
+__global__ void k_build_argmin(const double* __restrict__ tab, int n, const double* __restrict__ Tvals, int nT,
+                               int* __restrict__ out)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nT) return;
+    const double t = Tvals[q];
+    int best = 0;
+    double bd = fabs(tab[1] - t);
+    for (int r = 1; r < n; r++) {
+        double d = fabs(tab[(size_t)r * NC + 1] - t);
+        if (d < bd) { bd = d; best = r; }
+    }
+    out[q] = best;
+}
+
+// ------------------------------------------------------------------------------------------------ noise tape RNG
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void k_fill_noise(double* __restrict__ tape, int N, int L, unsigned long long seed, unsigned epoch,
+                             long long env_offset, double sigma)
+{
+    long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)N * L) return;
+    int c = (int)(g % L);
+    long long e = g / L + env_offset;
+    unsigned o[4];
+    philox4x32_10((unsigned)c, epoch, (unsigned)e, (unsigned)(e >> 32), (unsigned)seed, (unsigned)(seed >> 32), o);
+    unsigned long long a = ((unsigned long long)o[0] << 21) ^ (o[1] >> 11);   // 53 bits
+    unsigned long long b = ((unsigned long long)o[2] << 21) ^ (o[3] >> 11);
+    double u1 = ((double)(a & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
+    double u2 = ((double)(b & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
+    tape[g] = sigma * (sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+}
+
+// ------------------------------------------------------------------------------------------------ the env step
+__device__ __forceinline__ void load_regs(const DevParams& P, int e, Regs& R)
+{
+    R.i = P.st_i[e]; R.j = P.st_j[e]; R.k = P.st_k[e]; R.flags = P.st_flags[e]; R.act_d = P.st_actd[e];
+    R.nctr = P.st_nctr[e]; R.nchg = P.st_nchg[e]; R.epp = P.st_epp[e]; R.cum = P.st_cum[e];
+}
+__device__ __forceinline__ void store_regs(const DevParams& P, int e, const Regs& R)
+{
+    P.st_i[e] = R.i; P.st_j[e] = R.j; P.st_k[e] = R.k; P.st_flags[e] = R.flags; P.st_actd[e] = R.act_d;
+    P.st_nctr[e] = R.nctr; P.st_nchg[e] = R.nchg; P.st_epp[e] = R.epp; P.st_cum[e] = R.cum;
+}
+
+// :346-357 -> action id 0..4, or -1 for an invalid discrete action
+__device__ __forceinline__ int decode_action(const void* actions, int kind, size_t idx, int previous)
+{
+    if (kind == PTG_ACT_F32) {
+        // prob_thre[ival] = -1 + ival*0.4 in float64 (:151-155); first threshold > action picks actions[ival-1] (:351-355)
+        const double a = (double)((const float*)actions)[idx];
+        const double ival = (1.0 - (-1.0)) / 5;
+        int out = previous;
+        bool hit = false;
+        for (int q = 0; q < 6; q++) {
+            double thr = -1.0 + q * ival;
+            if (!hit && thr > a) { out = (q == 0) ? 4 : q - 1; hit = true; }
+        }
+        return out;
+    }
+    long long a = (kind == PTG_ACT_I64) ? ((const long long*)actions)[idx] : (long long)((const int*)actions)[idx];
+    if (a < -5 || a > 4) return -1;
+    return (int)(a < 0 ? a + 5 : a);      // python list indexing: actions[-1] is full_load
+}
+
+// Integer state machine of step() (:339-440) and _perform_sim_step (:525-557).  Returns the record index.
+__device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, int e, bool& changed)
+{
+    unsigned f = R.flags;
+    int s = f & 7, hot = (f >> 3) & 1, sb = (f >> 4) & 1, su = (f >> 5) & 1, pp = (f >> 6) & 7, fq = (f >> 9) & 7;
+    const unsigned mset = (f >> 15) & 3;
+    int tkey = (int)(f >> 17);
+    // :339-342 hot/cold hysteresis on the previous catalyst temperature
+    if (tkey <= P.key_cold_max) hot = 0;
+    else if (tkey >= P.key_hot_min) hot = 1;
+    const int prev = s;
+    const int S = P.S;
+    int i = R.i, j = R.j, table;
+    // :368-440 dispatch
+    int kind;   // 0 continue, 1 _standby, 2 _cooldown, 3 _startup, 4 _partial, 5 _full
+    if (act == 0) kind = (s == 0) ? 0 : 1;
+    else if (act == 1) kind = (s == 1) ? 0 : 2;
+    else if (act == 2) kind = (s <= 1) ? 3 : 0;
+    else if (act == 3) kind = (s == 4) ? 4 : 0;
+    else kind = (s == 3) ? 5 : 0;
+
+    if (kind == 0) {                                       // _cont (:559-570)
+        table = (s == 0) ? (sb ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN)
+              : (s == 1) ? PTG_T_COOLDOWN
+              : (s == 2) ? (su ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD)
+              : (s == 3) ? part_tid(pp) : full_tid(fq);
+        j += 1;
+    } else if (kind <= 3) {                                // _standby / _cooldown / _startup (:572-625)
+        int dest;
+        if (kind == 1) { s = 0; sb = (tkey <= P.key_standby_max); table = sb ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN; dest = sb ? 1 : 2; }
+        else if (kind == 2) { s = 1; table = PTG_T_COOLDOWN; dest = 0; }
+        else { s = 2; pp = 0; fq = 0; su = hot; table = su ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD; dest = su ? 4 : 3; }
+        const int idx = P.argidx[dest * P.nT + tkey];
+        double z = 0.0;
+        if (P.tape_len > 0) z = P.tape[(size_t)e * P.tape_len + (R.nctr % P.tape_len)];
+        R.nctr += 1;
+        double x = (double)idx + z;                        // int(max(idx + normal, 0)) (:584-585)
+        if (0 > x) x = 0;
+        i = (int)x;
+        j = 1;
+    } else if (kind == 4) {                                // _partial (:627-691)
+        s = 3;
+        const int time_op = i + j * S;
+        if (fq == 0) {
+            if (time_op < P.t2_start_f_p) { pp = 0; i = P.argidx[5 * P.nT + tkey]; j = 1; }
+            else { pp = 5; i = 0; j = 1; }
+        } else if (fq == 1) {
+            if (time_op < P.t1_p_f_p) { pp = 5; i = P.i_full; j = P.j_full; }
+            else if (P.t1_p_f_p < time_op && time_op < P.t2_p_f_p) { pp = 1; j += 1; }
+            else if (P.t2_p_f_p < time_op && time_op < P.t_p_f) { pp = 1; i = P.t2_p_f_p; j = 1; }
+            else if (P.t_p_f < time_op && time_op < P.t34_p_f_p) { pp = 2; i = P.t3_p_f_p; j = 1; }
+            else if (P.t34_p_f_p < time_op && time_op < P.t45_p_f_p) { pp = 3; i = P.t4_p_f_p; j = 1; }
+            else if (P.t45_p_f_p < time_op && time_op < P.t5_p_f_p) { pp = 4; i = P.t5_p_f_p; j = 1; }
+            else { pp = 5; i = 0; j = 1; }
+        } else { pp = 5; i = 0; j = 1; }
+        table = part_tid(pp);
+    } else {                                               // _full (:693-757)
+        s = 4;
+        const int time_op = i + j * S;
+        if (pp == 0) {
+            fq = (time_op < P.t1_start_p_f) ? 0 : 1; i = 0; j = 1;
+        } else if (pp == 5) {
+            if (time_op < P.t1_f_p_f) { fq = 1; i = P.i_full; j = P.j_full; }
+            else if (P.t1_f_p_f < time_op && time_op < P.t_f_p) { fq = 2; j += 1; }
+            else if (P.t_f_p < time_op && time_op < P.t23_f_p_f) { fq = 2; i = P.t2_f_p_f; j = 1; }
+            else if (P.t23_f_p_f < time_op && time_op < P.t34_f_p_f) { fq = 3; i = P.t3_f_p_f; j = 1; }
+            else if (P.t34_f_p_f < time_op && time_op < P.t45_f_p_f) { fq = 4; i = P.t4_f_p_f; j = 1; }
+            else if (P.t45_f_p_f < time_op && time_op < P.t5_f_p_f) { fq = 5; i = P.t5_f_p_f; j = 1; }
+            else { fq = 1; i = 0; j = 1; }
+        } else { fq = 1; i = 0; j = 1; }
+        table = full_tid(fq);
+    }
+    // _perform_sim_step (:525-557) against the virtual table [rows | splice-or-last-row padding]
+    const int2 tm = P.tabmeta[table];
+    const int n = tm.x;
+    const int start = i + (j - 1) * S;
+    int r;
+    if (start + S < n) {
+        r = start;
+    } else {
+        const int over = start + S - n;
+        if (table <= PTG_T_STARTUP_HOT) {                   // change_operation: startup -> partial load
+            s = 3;
+            if (over < S) { r = start; i = over; j = 0; }
+            else r = n;
+        } else {
+            r = min(start, n);
+        }
+    }
+    changed = (prev != s);
+    R.i = i; R.j = j;
+    R.flags = (unsigned)s | (hot << 3) | (sb << 4) | (su << 5) | (pp << 6) | (fq << 9) | ((unsigned)act << 12) |
+              (mset << 15) | ((unsigned)tkey << 17);
+    return tm.y + r;
+}
+
+template <typename OUT>
+__device__ __forceinline__ void write_price_features(const DevParams& P, OUT* row, unsigned mset, int H, int D)
+{
+    const size_t hb = (size_t)mset * P.hstride + H, db = (size_t)mset * P.dstride + D;
+    const int PA = P.PA;
+    if (P.mod) {          // Pot_Reward (normalised), Part_Full (:238-239)
+        for (int q = 0; q < PA; q++) row[q] = (OUT)P.featA[hb + q];
+        for (int q = 0; q < PA; q++) row[PA + q] = (OUT)P.featB[hb + q];
+    } else {              // Elec_Price, Gas_Price, EUA_Price (:223-225)
+        for (int q = 0; q < PA; q++) row[q] = (OUT)P.featA[hb + q];
+        row[PA] = (OUT)P.gas_n[db]; row[PA + 1] = (OUT)P.gas_n[db + 1];
+        row[PA + 2] = (OUT)P.eua_n[db]; row[PA + 3] = (OUT)P.eua_n[db + 1];
+    }
+}
+
+// reset() (:483-506): takes the env's next episode, _initialize_op_rew (:105-138), writes the observation row
+template <typename OUT>
+__device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, OUT* row)
+{
+    if (P.E > 0) {
+        R.act_d = P.eps_ind[R.epp] * P.eps_len_d;
+        R.epp += P.ep_stride;
+        if (R.epp >= P.E) R.epp %= P.E;
+    } else {
+        R.act_d = 0;
+    }
+    const unsigned keep = R.flags & ((7u << 12) | (3u << 15));       // current_action survives reset(); market set is fixed
+    R.flags = 1u | keep | ((unsigned)P.key_init << 17);              // cooldown, cold, standby_down, startup_cold, op1, op2
+    R.i = P.i_reset; R.j = 0; R.k = 0; R.cum = 0.0; R.nchg = 0;
+    if (row) {
+        const unsigned mset = (R.flags >> 15) & 3;
+        write_price_features<OUT>(P, row, mset, R.act_d * 24, R.act_d);
+        OUT* p = row + (P.mod ? 2 * P.PA : P.PA + 4);
+        p[0] = (OUT)1.0;
+        p[1] = (OUT)((P.T_init - P.T_lo) / P.T_rng);
+        p[2] = (OUT)((P.reset_flow[0] - P.h2_lo) / P.h2_rng);
+        p[3] = (OUT)((P.reset_flow[1] - P.ch4_lo) / P.ch4_rng);
+        p[4] = (OUT)((P.reset_flow[2] - P.h2r_lo) / P.h2r_rng);
+        p[5] = (OUT)((P.reset_flow[3] - P.h2o_lo) / P.h2o_rng);
+        p[6] = (OUT)((P.reset_flow[4] - P.heat_lo) / P.heat_rng);
+        p[7] = (OUT)0.0;      // sin(0)
+        p[8] = (OUT)1.0;      // cos(0)
+    }
+}
+
+// One env step.  obs_row / final_row / info_row may be null.  Returns terminated.
+template <typename OUT, bool INFO>
+__device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int act, OUT* obs_row, OUT* rew_out,
+                                         double* info_row)
+{
+    bool changed;
+    const int ridx = step_ints(P, R, act, e, changed);
+    const Rec rec = P.rec[ridx];
+    R.flags = (R.flags & 0x1FFFFu) | ((unsigned)rec.tkey << 17);       // Meth_T_cat = op[-1, 1] (:452)
+    const unsigned mset = (R.flags >> 15) & 3;
+    const int s = R.flags & 7;
+    // :442-450 clock and price columns at time (k+1)*dt
+    const int k1 = R.k + 1;
+    const int secs = k1 * P.sim_step;
+    int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
+    if (H + P.PA > P.n_hours || D + 2 > P.n_days || H < 0 || D < 0) {
+        atomicOr(P.err, 2);
+        H = max(0, min(H, P.n_hours - P.PA)); D = max(0, min(D, P.n_days - 2));
+    }
+    const double el = P.el[(size_t)mset * P.hstride + H];
+    const double gas = P.gas[(size_t)mset * P.dstride + D];
+    const double eua = P.eua[(size_t)mset * P.dstride + D];
+    const double2 sc = P.sincos[k1 <= P.eps_sim_steps ? k1 : P.eps_sim_steps];
+    const double2 setc = P.setc[mset];
+    const double H2 = rec.m[0], CH4 = rec.m[1], H2r = rec.m[2], H2O = rec.m[3], heat = rec.m[4];
+    // :280-334 reward, operand order of the reference
+    const double ch4_vol = CH4 * P.c_mol;
+    const double h2r_vol = H2r * P.c_mol;
+    const double Q_ch4 = ch4_vol * P.Hu_ch4 * 1000;
+    const double Q_h2r = h2r_vol * P.Hu_h2 * 1000;
+    const double ch4_rev = (Q_ch4 + Q_h2r) * gas;
+    const double power_chp = Q_ch4 * P.eta_chp * setc.x;
+    const double Q_chp = Q_ch4 * P.one_m_eta_chp * setc.x;
+    const double chp_rev = power_chp * P.eeg;
+    const double Q_steam = H2O * P.dt_cp_evap / 3600;
+    const double steam_rev = (Q_steam + Q_chp) * P.heat_price;
+    const double h2_vol = H2 * P.c_mol;
+    const double o2_vol = 0.5 * h2_vol * 3600;
+    const double o2_rev = o2_vol * P.o2_price;
+    const double co2 = CH4 * P.M_co2 / 1000;
+    const double eua_rev = co2 / 1000 * 3600 * eua * 100;
+    const double cost_heat = heat / 1000 * el;
+    const double load = h2_vol / P.max_h2;
+    double eta;
+    if (load < P.min_load) {
+        eta = 0.02;
+    } else {
+        const double l2 = load * load, inv = 1.0 / load;
+        eta = 0.598 - 0.325 * l2 + 0.218 * (l2 * load) + 0.01 * inv - P.c_m2 * (inv * inv) + P.c_m3 * (inv * inv * inv);
+    }
+    const double cost_elz = h2_vol * P.Hu_h2 * 1000 / eta * el;
+    const double cost_el = cost_heat + cost_elz;
+    const double water_elz = H2 * P.M_h2o / 1000 * 3600;
+    const double cost_water = (H2O + water_elz) / P.rho * P.water_price;
+    double rew = (ch4_rev + chp_rev + steam_rev + eua_rev + o2_rev - cost_el - cost_water) * P.sim_step_d / 3600;
+    R.cum += rew;
+    if (changed) { rew -= setc.y; R.nchg += 1; }
+    *rew_out = (OUT)rew;
+    // :206-217 + :219-249 observation row
+    if (obs_row) {
+        write_price_features<OUT>(P, obs_row, mset, H, D);
+        OUT* p = obs_row + (P.mod ? 2 * P.PA : P.PA + 4);
+        p[0] = (OUT)s;
+        p[1] = (OUT)((rec.T - P.T_lo) / P.T_rng);
+        p[2] = (OUT)((H2 - P.h2_lo) / P.h2_rng);
+        p[3] = (OUT)((CH4 - P.ch4_lo) / P.ch4_rng);
+        p[4] = (OUT)((H2r - P.h2r_lo) / P.h2r_rng);
+        p[5] = (OUT)((H2O - P.h2o_lo) / P.h2o_rng);
+        p[6] = (OUT)((heat - P.heat_lo) / P.heat_rng);
+        p[7] = (OUT)sc.x;
+        p[8] = (OUT)sc.y;
+    }
+    if (INFO && info_row) {   // :251-278
+        const size_t hb = (size_t)mset * P.hstride + H;
+        info_row[0] = (double)R.k; info_row[1] = el; info_row[2] = gas; info_row[3] = eua;
+        info_row[4] = (double)s; info_row[5] = (double)act; info_row[6] = (double)((R.flags >> 3) & 1);
+        info_row[7] = rec.T; info_row[8] = H2; info_row[9] = CH4; info_row[10] = H2O; info_row[11] = heat;
+        info_row[12] = ch4_rev; info_row[13] = steam_rev; info_row[14] = o2_rev; info_row[15] = eua_rev;
+        info_row[16] = chp_rev; info_row[17] = -cost_heat; info_row[18] = -cost_elz; info_row[19] = -cost_water;
+        info_row[20] = rew; info_row[21] = R.cum;
+        info_row[22] = P.pot_raw[hb]; info_row[23] = P.pf_raw[hb];
+    }
+    const bool term = (R.k == P.eps_sim_steps - 6);   // :508-511, tested before k += 1
+    R.k = k1;
+    return term;
+}
+
+// Finished episodes are compacted with a wave ballot: one atomic per wave, rank = popcount of lower done lanes.
+__device__ __forceinline__ void push_finished(const DevParams& P, bool done, int e, double ret, int len)
+{
+    const unsigned long long m = __ballot(done);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(P.fin_count, __popcll(m));
+    base = __shfl(base, leader);
+    if (done) {
+        const int slot = (base + __popcll(m & ((1ull << lane) - 1ull))) % P.fin_cap;
+        P.fin_ret[slot] = ret; P.fin_len[slot] = len; P.fin_env[slot] = e;
+    }
+}
+
+template <typename OUT, bool INFO>
+__global__ void __launch_bounds__(256)
+k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT* __restrict__ obs, OUT* __restrict__ rew,
+       uint8_t* __restrict__ done, OUT* __restrict__ final_obs, double* __restrict__ info)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < P.N;
+    bool term = false;
+    Regs R;
+    double ret = 0.0;
+    int len = 0;
+    if (live) {
+        load_regs(P, e, R);
+        const int act = decode_action(actions, action_kind, e, (R.flags >> 12) & 7);
+        if (act < 0) {
+            atomicOr(P.err, 1);
+            rew[e] = (OUT)NAN;
+            done[e] = 0;
+        } else {
+            OUT* row = obs + (size_t)e * P.F;
+            double* irow = (INFO && info) ? info + (size_t)e * PTG_N_INFO : nullptr;
+            OUT r;
+            term = env_step<OUT, INFO>(P, R, e, act, row, &r, irow);
+            rew[e] = r;
+            done[e] = term ? 1 : 0;
+            if (term) {
+                if (final_obs) for (int q = 0; q < P.F; q++) final_obs[(size_t)e * P.F + q] = row[q];
+                ret = R.cum - (double)R.nchg * P.setc[(R.flags >> 15) & 3].y;
+                len = R.k;
+                reset_env<OUT>(P, R, row);
+            }
+            store_regs(P, e, R);
+        }
+    }
+    push_finished(P, live && term, e, ret, len);
+}
+
+template <typename OUT>
+__global__ void __launch_bounds__(256)
+k_rollout(const DevParams P, const void* __restrict__ actions, int action_kind, int T, OUT* __restrict__ obs,
+          OUT* __restrict__ rew, uint8_t* __restrict__ done)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < P.N;
+    Regs R;
+    if (live) load_regs(P, e, R);
+    bool bad = false;
+    for (int t = 0; t < T; t++) {
+        bool term = false;
+        double ret = 0.0;
+        int len = 0;
+        if (live && !bad) {
+            const size_t g = (size_t)t * P.N + e;
+            const int act = decode_action(actions, action_kind, g, (R.flags >> 12) & 7);
+            if (act < 0) {
+                atomicOr(P.err, 1);
+                bad = true;
+            } else {
+                OUT* row = obs + g * P.F;
+                OUT r;
+                term = env_step<OUT, false>(P, R, e, act, row, &r, nullptr);
+                rew[g] = r;
+                done[g] = term ? 1 : 0;
+                if (term) {
+                    ret = R.cum - (double)R.nchg * P.setc[(R.flags >> 15) & 3].y;
+                    len = R.k;
+                    reset_env<OUT>(P, R, row);
+                }
+            }
+        }
+        push_finished(P, live && term, e, ret, len);
+    }
+    if (live) store_regs(P, e, R);
+}
+
+template <typename OUT>
+__global__ void k_reset(const DevParams P, const uint8_t* __restrict__ mask, OUT* __restrict__ obs)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.N) return;
+    if (mask && !mask[e]) return;
+    Regs R;
+    load_regs(P, e, R);
+    reset_env<OUT>(P, R, obs ? obs + (size_t)e * P.F : nullptr);
+    store_regs(P, e, R);
+}
+
+__global__ void k_init_state(const DevParams P, int first_ptr_mod, int have_plan)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.N) return;
+    if (have_plan) {
+        P.st_epp[e] = P.E > 0 ? (int)(((long long)first_ptr_mod + e) % P.E) : 0;
+        return;
+    }
+    P.st_i[e] = 0; P.st_j[e] = 0; P.st_k[e] = 0; P.st_actd[e] = 0; P.st_nctr[e] = 0; P.st_nchg[e] = 0; P.st_epp[e] = 0;
+    P.st_flags[e] = 1u | (1u << 12) | ((unsigned)P.key_init << 17);   // cooldown, current_action = 'cooldown' (:143)
+    P.st_cum[e] = 0.0;
+}
+
+}  // namespace
+
+// ================================================================================================= host side
+struct ptg_env {
+    ptg_config cfg;
+    int n = 0, device = 0, n_sets = 0, F = 0, S = 0;
+    bool reset_done = false;
+    DevParams P;
+    std::vector<void*> allocs;
+    std::vector<double> Tvals;
+    std::vector<int> tab_rows, rec_base;
+    double* d_tape = nullptr;
+    int tape_len = 0;
+    unsigned noise_epoch = 0;
+    long long env_offset = 0;
+    double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
+    int* d_eps_ind = nullptr;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int set_err(ptg_env* h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return set_err(h, PTG_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(ptg_env* h, T** p, size_t count)
+{
+    void* q = nullptr;
+    HIP_TRY(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+
+template <typename T>
+int dev_upload(ptg_env* h, T** p, const T* src, size_t count)
+{
+    int rc = dev_alloc(h, p, count);
+    if (rc) return rc;
+    if (count) HIP_TRY(h, hipMemcpy(*p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// math.sin / math.cos are two separate libm calls in the reference (:449-450)
+__attribute__((noinline)) double host_sin(double x) { return std::sin(x); }
+__attribute__((noinline)) double host_cos(double x) { return std::cos(x); }
+
+inline int grid_for(long long n, int block) { return (int)((n + block - 1) / block); }
+
+int launch_check(ptg_env* h, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(h, PTG_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+int build_tables(ptg_env* h, const ptg_tables* tb)
+{
+    const int S = h->S;
+    // distinct catalyst temperatures (every table's T column + the initial temperature), sorted
+    std::vector<double>& Tv = h->Tvals;
+    size_t total_rows = 0;
+    for (int t = 0; t < NT; t++) {
+        if (tb->rows[t] < 1 || !tb->data_host[t]) return set_err(h, PTG_E_INVALID, "table %d is empty", t);
+        total_rows += tb->rows[t];
+        for (int r = 0; r < tb->rows[t]; r++) {
+            double T = tb->data_host[t][(size_t)r * NC + 1];
+            if (!(T == T)) return set_err(h, PTG_E_INVALID, "NaN temperature in table %d row %d", t, r);
+            Tv.push_back(T);
+        }
+    }
+    if (tb->rows[PTG_T_OP1_START_P] < S) return set_err(h, PTG_E_INVALID, "op1_start_p is shorter than one step");
+    Tv.push_back(h->cfg.t_cat_initial);
+    std::sort(Tv.begin(), Tv.end());
+    Tv.erase(std::unique(Tv.begin(), Tv.end()), Tv.end());
+    const int nT = (int)Tv.size();
+    if (nT >= (1 << 15)) return set_err(h, PTG_E_INVALID, "more than 32767 distinct catalyst temperatures (%d)", nT);
+    auto key_of = [&](double T) { return (int)(std::lower_bound(Tv.begin(), Tv.end(), T) - Tv.begin()); };
+
+    // raw tables + per-row keys on the device (only needed while building)
+    std::vector<double> raw(total_rows * NC);
+    std::vector<int> rowkey(total_rows), raw_base(NT);
+    h->tab_rows.resize(NT); h->rec_base.resize(NT);
+    size_t off = 0, rec_total = 0;
+    for (int t = 0; t < NT; t++) {
+        raw_base[t] = (int)off;
+        h->tab_rows[t] = tb->rows[t];
+        h->rec_base[t] = (int)rec_total;
+        memcpy(&raw[off * NC], tb->data_host[t], sizeof(double) * NC * tb->rows[t]);
+        for (int r = 0; r < tb->rows[t]; r++) rowkey[off + r] = key_of(tb->data_host[t][(size_t)r * NC + 1]);
+        off += tb->rows[t];
+        rec_total += (size_t)tb->rows[t] + 1;
+    }
+    double* d_raw = nullptr; int* d_key = nullptr; double* d_T = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_raw, raw.size() * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void**)&d_key, rowkey.size() * sizeof(int)));
+    HIP_TRY(h, hipMemcpy(d_raw, raw.data(), raw.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_key, rowkey.data(), rowkey.size() * sizeof(int), hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = dev_upload(h, &d_T, Tv.data(), Tv.size()))) return rc;
+    Rec* d_rec; int* d_arg; int2* d_meta;
+    if ((rc = dev_alloc(h, &d_rec, rec_total))) return rc;
+    if ((rc = dev_alloc(h, &d_arg, (size_t)N_DEST * nT))) return rc;
+    std::vector<int2> meta(NT);
+    for (int t = 0; t < NT; t++) meta[t] = make_int2(h->tab_rows[t], h->rec_base[t]);
+    if ((rc = dev_upload(h, &d_meta, meta.data(), meta.size()))) return rc;
+    const double* d_op1 = d_raw + (size_t)raw_base[PTG_T_OP1_START_P] * NC;
+    const int* d_op1key = d_key + raw_base[PTG_T_OP1_START_P];
+    for (int t = 0; t < NT; t++) {
+        const int n = h->tab_rows[t];
+        hipLaunchKernelGGL(k_build_records, dim3(grid_for(n + 1, 128)), dim3(128), 0, 0, d_raw + (size_t)raw_base[t] * NC,
+                           d_key + raw_base[t], n, d_op1, d_op1key, t <= PTG_T_STARTUP_HOT ? 1 : 0, S, d_rec + h->rec_base[t]);
+        if ((rc = launch_check(h, "k_build_records"))) return rc;
+    }
+    for (int d = 0; d < N_DEST; d++) {
+        const int t = DEST_TID[d];
+        hipLaunchKernelGGL(k_build_argmin, dim3(grid_for(nT, 128)), dim3(128), 0, 0, d_raw + (size_t)raw_base[t] * NC,
+                           h->tab_rows[t], d_T, nT, d_arg + (size_t)d * nT);
+        if ((rc = launch_check(h, "k_build_argmin"))) return rc;
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    DevParams& P = h->P;
+    P.rec = d_rec; P.argidx = d_arg; P.tabmeta = d_meta; P.Tvals = d_T; P.nT = nT;
+    P.key_init = key_of(h->cfg.t_cat_initial);
+    P.key_cold_max = (int)(std::upper_bound(Tv.begin(), Tv.end(), h->cfg.t_cat_startup_cold) - Tv.begin()) - 1;
+    P.key_hot_min = key_of(h->cfg.t_cat_startup_hot);
+    P.key_standby_max = (int)(std::upper_bound(Tv.begin(), Tv.end(), h->cfg.t_cat_standby) - Tv.begin()) - 1;
+    // reset state (:117-122): i = argmin |cooldown.T - T_initial|, flows of that single row
+    HIP_TRY(h, hipMemcpy(&P.i_reset, d_arg + P.key_init, sizeof(int), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 5; c++) P.reset_flow[c] = tb->data_host[PTG_T_COOLDOWN][(size_t)P.i_reset * NC + 2 + c];
+    P.T_init = h->cfg.t_cat_initial;
+    (void)hipFree(d_raw); (void)hipFree(d_key);
+    return 0;
+}
+
+int build_market(ptg_env* h, const ptg_market* sets, int n_sets)
+{
+    const ptg_config& c = h->cfg;
+    DevParams& P = h->P;
+    const int nh = sets[0].n_hours, nd = sets[0].n_days;
+    if (nh < c.price_ahead || nd < 2) return set_err(h, PTG_E_INVALID, "market series too short");
+    for (int s = 0; s < n_sets; s++) {
+        if (sets[s].n_hours != nh || sets[s].n_days != nd) return set_err(h, PTG_E_INVALID, "market sets differ in length");
+        if (!sets[s].el_host || !sets[s].pot_rew_host || !sets[s].part_full_host || !sets[s].gas_host || !sets[s].eua_host)
+            return set_err(h, PTG_E_INVALID, "market set %d has a null series", s);
+    }
+    std::vector<double> el((size_t)n_sets * nh), fa((size_t)n_sets * nh), fb((size_t)n_sets * nh), pot((size_t)n_sets * nh),
+        pf((size_t)n_sets * nh), gas((size_t)n_sets * nd), eua((size_t)n_sets * nd), gasn((size_t)n_sets * nd), euan((size_t)n_sets * nd);
+    std::vector<double2> setc(n_sets);
+    for (int s = 0; s < n_sets; s++) {
+        const ptg_market& m = sets[s];
+        for (int t = 0; t < nh; t++) {
+            const size_t g = (size_t)s * nh + t;
+            el[g] = m.el_host[t]; pot[g] = m.pot_rew_host[t]; pf[g] = m.part_full_host[t];
+            if (c.raw_modified) {      // :208 pot_rew_n ; Part_Full stays raw (:239)
+                fa[g] = (m.pot_rew_host[t] - m.rew_l_b) / (m.rew_u_b - m.rew_l_b);
+                fb[g] = m.part_full_host[t];
+            } else {                   // :209 el_n
+                fa[g] = (m.el_host[t] - c.el_l_b) / (c.el_u_b - c.el_l_b);
+                fb[g] = 0.0;
+            }
+        }
+        for (int d = 0; d < nd; d++) {
+            const size_t g = (size_t)s * nd + d;
+            gas[g] = m.gas_host[d]; eua[g] = m.eua_host[d];
+            gasn[g] = (m.gas_host[d] - c.gas_l_b) / (c.gas_u_b - c.gas_l_b);     // :210
+            euan[g] = (m.eua_host[d] - c.eua_l_b) / (c.eua_u_b - c.eua_l_b);     // :211
+        }
+        setc[s] = make_double2(m.scenario == 3 ? 1.0 : 0.0, m.r_0 * c.state_change_penalty);   // :76-77, :332
+    }
+    int rc;
+    double *d_el, *d_fa, *d_fb, *d_gas, *d_eua, *d_gasn, *d_euan; double2* d_setc;
+    if ((rc = dev_upload(h, &d_el, el.data(), el.size()))) return rc;
+    if ((rc = dev_upload(h, &d_fa, fa.data(), fa.size()))) return rc;
+    if ((rc = dev_upload(h, &d_fb, fb.data(), fb.size()))) return rc;
+    if ((rc = dev_upload(h, &d_gas, gas.data(), gas.size()))) return rc;
+    if ((rc = dev_upload(h, &d_eua, eua.data(), eua.size()))) return rc;
+    if ((rc = dev_upload(h, &d_gasn, gasn.data(), gasn.size()))) return rc;
+    if ((rc = dev_upload(h, &d_euan, euan.data(), euan.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_pot_raw, pot.data(), pot.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_pf_raw, pf.data(), pf.size()))) return rc;
+    if ((rc = dev_upload(h, &d_setc, setc.data(), setc.size()))) return rc;
+    P.pot_raw = h->d_pot_raw; P.pf_raw = h->d_pf_raw;
+    P.el = d_el; P.featA = d_fa; P.featB = d_fb; P.gas = d_gas; P.eua = d_eua; P.gas_n = d_gasn; P.eua_n = d_euan; P.setc = d_setc;
+    P.n_hours = nh; P.n_days = nd; P.hstride = nh; P.dstride = nd;
+    return 0;
+}
+
+hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+int collect_error(ptg_env* h, hipStream_t st)
+{
+    int flag = 0;
+    HIP_TRY(h, hipMemcpyAsync(&flag, h->P.err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (flag) {
+        HIP_TRY(h, hipMemsetAsync(h->P.err, 0, sizeof(int), st));
+        if (flag & 1) return set_err(h, PTG_E_ACTION, "a discrete action outside [-5, 4] was passed (the reference raises IndexError)");
+        return set_err(h, PTG_E_RANGE, "a price index left the market series (episode longer than the data)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptg_abi_version(void) { return PTG_ABI_VERSION; }
+
+const char* ptg_last_error(const ptg_env* env) { return env ? env->err.c_str() : g_create_err.c_str(); }
+
+int ptg_num_envs(const ptg_env* env) { return env ? env->n : PTG_E_INVALID; }
+int ptg_obs_dim(const ptg_env* env) { return env ? env->F : PTG_E_INVALID; }
+
+void ptg_destroy(ptg_env* env)
+{
+    if (!env) return;
+    (void)hipSetDevice(env->device);
+    for (void* p : env->allocs) (void)hipFree(p);
+    if (env->d_tape) (void)hipFree(env->d_tape);
+    if (env->d_eps_ind) (void)hipFree(env->d_eps_ind);
+    delete env;
+}
+
+int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market* sets, int n_sets, int n_envs,
+               int device_id, ptg_env** out)
+{
+    if (!cfg || !tables || !sets || !out) return set_err(nullptr, PTG_E_INVALID, "ptg_create: null argument");
+    if (n_envs <= 0 || n_sets < 1 || n_sets > PTG_MAX_MARKET_SETS) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad n_envs / n_sets");
+    if (cfg->time_step_op <= 0 || cfg->sim_step <= 0 || cfg->price_ahead < 1 || cfg->price_ahead > 64)
+        return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad sim_step / time_step_op / price_ahead");
+    if (cfg->out_dtype != PTG_OUT_F32 && cfg->out_dtype != PTG_OUT_F64) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad out_dtype");
+    if (cfg->eps_sim_steps < 7) return set_err(nullptr, PTG_E_INVALID, "ptg_create: eps_sim_steps must be >= 7");
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0)
+        return set_err(nullptr, PTG_E_HIP, "no HIP device available (%s): libptg_env has no CPU path", hipGetErrorString(he));
+    if (device_id < 0 || device_id >= ndev) return set_err(nullptr, PTG_E_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    he = hipSetDevice(device_id);
+    if (he != hipSuccess) return set_err(nullptr, PTG_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(he));
+
+    ptg_env* h = new ptg_env();
+    h->cfg = *cfg; h->n = n_envs; h->device = device_id; h->n_sets = n_sets;
+    h->S = (int)((double)cfg->sim_step / (double)cfg->time_step_op);     // :66
+    h->F = cfg->raw_modified ? 2 * cfg->price_ahead + 9 : cfg->price_ahead + 4 + 9;
+    memset(&h->P, 0, sizeof h->P);
+    DevParams& P = h->P;
+    int rc = 0;
+    auto fail = [&](int code) { g_create_err = h->err; ptg_destroy(h); return code; };
+    if (h->S < 1) { set_err(h, PTG_E_INVALID, "step_size < 1"); return fail(PTG_E_INVALID); }
+    if ((rc = build_tables(h, tables))) return fail(rc);
+    if ((rc = build_market(h, sets, n_sets))) return fail(rc);
+
+    P.N = n_envs; P.S = h->S; P.sim_step = cfg->sim_step; P.eps_sim_steps = cfg->eps_sim_steps; P.PA = cfg->price_ahead;
+    P.F = h->F; P.mod = cfg->raw_modified; P.eps_len_d = cfg->eps_len_d; P.E = 0; P.ep_stride = 0; P.tape_len = 0;
+    P.t1_start_p_f = cfg->time1_start_p_f; P.t2_start_f_p = cfg->time2_start_f_p; P.t_p_f = cfg->time_p_f; P.t_f_p = cfg->time_f_p;
+    P.t1_p_f_p = cfg->time1_p_f_p; P.t2_p_f_p = cfg->time2_p_f_p; P.t3_p_f_p = cfg->time3_p_f_p; P.t34_p_f_p = cfg->time34_p_f_p;
+    P.t4_p_f_p = cfg->time4_p_f_p; P.t45_p_f_p = cfg->time45_p_f_p; P.t5_p_f_p = cfg->time5_p_f_p; P.t1_f_p_f = cfg->time1_f_p_f;
+    P.t2_f_p_f = cfg->time2_f_p_f; P.t23_f_p_f = cfg->time23_f_p_f; P.t3_f_p_f = cfg->time3_f_p_f; P.t34_f_p_f = cfg->time34_f_p_f;
+    P.t4_f_p_f = cfg->time4_f_p_f; P.t45_f_p_f = cfg->time45_f_p_f; P.t5_f_p_f = cfg->time5_f_p_f;
+    P.i_full = cfg->i_fully_developed; P.j_full = cfg->j_fully_developed;
+    P.c_mol = cfg->convert_mol_to_Nm3; P.Hu_ch4 = cfg->H_u_CH4; P.Hu_h2 = cfg->H_u_H2;
+    P.dt_cp_evap = cfg->dt_water * cfg->cp_water + cfg->h_H2O_evap;      // :296
+    P.heat_price = cfg->heat_price; P.o2_price = cfg->o2_price; P.eeg = cfg->eeg_el_price; P.eta_chp = cfg->eta_CHP;
+    P.one_m_eta_chp = 1 - cfg->eta_CHP; P.M_co2 = cfg->Molar_mass_CO2; P.M_h2o = cfg->Molar_mass_H2O; P.rho = cfg->rho_water;
+    P.water_price = cfg->water_price; P.min_load = cfg->min_load_electrolyzer; P.max_h2 = cfg->max_h2_volumeflow;
+    P.c_m2 = 1.68 * std::pow(10.0, -3.0);                               // python: 1.68 * 10 ** (-3) (:316)
+    P.c_m3 = 2.51 * std::pow(10.0, -5.0);                               // python: 2.51 * 10 ** (-5) (:317)
+    P.sim_step_d = (double)cfg->sim_step;
+    P.T_lo = cfg->T_l_b; P.T_rng = cfg->T_u_b - cfg->T_l_b; P.h2_lo = cfg->h2_l_b; P.h2_rng = cfg->h2_u_b - cfg->h2_l_b;
+    P.ch4_lo = cfg->ch4_l_b; P.ch4_rng = cfg->ch4_u_b - cfg->ch4_l_b; P.h2r_lo = cfg->h2_res_l_b; P.h2r_rng = cfg->h2_res_u_b - cfg->h2_res_l_b;
+    P.h2o_lo = cfg->h2o_l_b; P.h2o_rng = cfg->h2o_u_b - cfg->h2o_l_b; P.heat_lo = cfg->heat_l_b; P.heat_rng = cfg->heat_u_b - cfg->heat_l_b;
+
+    // temporal encoding (:442,449-450) for every step count of an episode, with the reference's growing argument
+    std::vector<double2> sc((size_t)cfg->eps_sim_steps + 1);
+    for (int k1 = 0; k1 <= cfg->eps_sim_steps; k1++) {
+        const double clock_hours = (double)((long long)k1 * cfg->sim_step) / 3600;
+        sc[k1] = make_double2(host_sin(2 * M_PI * clock_hours), host_cos(2 * M_PI * clock_hours));
+    }
+    double2* d_sc;
+    if ((rc = dev_upload(h, &d_sc, sc.data(), sc.size()))) return fail(rc);
+    P.sincos = d_sc;
+
+    if ((rc = dev_alloc(h, &P.st_i, n_envs)) || (rc = dev_alloc(h, &P.st_j, n_envs)) || (rc = dev_alloc(h, &P.st_k, n_envs)) ||
+        (rc = dev_alloc(h, &P.st_flags, n_envs)) || (rc = dev_alloc(h, &P.st_actd, n_envs)) || (rc = dev_alloc(h, &P.st_nctr, n_envs)) ||
+        (rc = dev_alloc(h, &P.st_nchg, n_envs)) || (rc = dev_alloc(h, &P.st_epp, n_envs)) || (rc = dev_alloc(h, &P.st_cum, n_envs)))
+        return fail(rc);
+    P.fin_cap = std::max(2 * n_envs, 1024);
+    if ((rc = dev_alloc(h, &P.fin_ret, P.fin_cap)) || (rc = dev_alloc(h, &P.fin_len, P.fin_cap)) ||
+        (rc = dev_alloc(h, &P.fin_env, P.fin_cap)) || (rc = dev_alloc(h, &P.fin_count, 1)) || (rc = dev_alloc(h, &P.err, 1)))
+        return fail(rc);
+    if (hipMemset(P.fin_count, 0, sizeof(int)) != hipSuccess || hipMemset(P.err, 0, sizeof(int)) != hipSuccess) {
+        set_err(h, PTG_E_HIP, "hipMemset failed");
+        return fail(PTG_E_HIP);
+    }
+    hipLaunchKernelGGL(k_init_state, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, P, 0, 0);
+    if ((rc = launch_check(h, "k_init_state"))) return fail(rc);
+    if (hipDeviceSynchronize() != hipSuccess) { set_err(h, PTG_E_HIP, "device synchronize failed after init"); return fail(PTG_E_HIP); }
+    *out = h;
+    return 0;
+}
+
+int ptg_set_market_assignment(ptg_env* h, const uint8_t* set_of_env_host)
+{
+    if (!h || !set_of_env_host) return set_err(h, PTG_E_INVALID, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<unsigned> fl(h->n);
+    HIP_TRY(h, hipMemcpy(fl.data(), h->P.st_flags, sizeof(unsigned) * h->n, hipMemcpyDeviceToHost));
+    for (int e = 0; e < h->n; e++) {
+        if (set_of_env_host[e] >= h->n_sets) return set_err(h, PTG_E_INVALID, "env %d: market set %d out of range", e, set_of_env_host[e]);
+        fl[e] = (fl[e] & ~(3u << 15)) | ((unsigned)set_of_env_host[e] << 15);
+    }
+    HIP_TRY(h, hipMemcpy(h->P.st_flags, fl.data(), sizeof(unsigned) * h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ptg_set_episode_plan(ptg_env* h, const double* eps_ind_host, int n, int64_t first_ptr, int64_t stride)
+{
+    if (!h || n < 0 || (n > 0 && !eps_ind_host) || first_ptr < 0 || stride < 0) return set_err(h, PTG_E_INVALID, "bad episode plan");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->d_eps_ind) { (void)hipFree(h->d_eps_ind); h->d_eps_ind = nullptr; }
+    h->P.E = n; h->P.eps_ind = nullptr; h->P.ep_stride = 0;
+    if (n > 0) {
+        std::vector<int> ei(n);
+        for (int q = 0; q < n; q++) ei[q] = (int)eps_ind_host[q];            // int(eps_ind[..] * eps_len_d) for integral entries (:60-61)
+        HIP_TRY(h, hipMalloc((void**)&h->d_eps_ind, sizeof(int) * n));
+        HIP_TRY(h, hipMemcpy(h->d_eps_ind, ei.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+        h->P.eps_ind = h->d_eps_ind;
+        h->P.ep_stride = (int)(stride % n);
+    }
+    hipLaunchKernelGGL(k_init_state, dim3(grid_for(h->n, 256)), dim3(256), 0, 0, h->P, n > 0 ? (int)(first_ptr % n) : 0, 1);
+    int rc = launch_check(h, "k_init_state");
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    return 0;
+}
+
+static int set_tape_len(ptg_env* h, int L)
+{
+    if (L != h->tape_len) {
+        if (h->d_tape) { (void)hipFree(h->d_tape); h->d_tape = nullptr; }
+        h->tape_len = 0;
+        if (L > 0) {
+            HIP_TRY(h, hipMalloc((void**)&h->d_tape, sizeof(double) * (size_t)h->n * L));
+            h->tape_len = L;
+        }
+    }
+    h->P.tape = h->d_tape; h->P.tape_len = h->tape_len;
+    return 0;
+}
+
+int ptg_set_noise_tape(ptg_env* h, const double* tape_host, int per_env_len)
+{
+    if (!h || per_env_len < 0 || (per_env_len > 0 && !tape_host)) return set_err(h, PTG_E_INVALID, "bad noise tape");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = set_tape_len(h, per_env_len);
+    if (rc) return rc;
+    if (per_env_len > 0)
+        HIP_TRY(h, hipMemcpy(h->d_tape, tape_host, sizeof(double) * (size_t)h->n * per_env_len, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(h->P.st_nctr, 0, sizeof(int) * h->n));
+    return 0;
+}
+
+int ptg_fill_noise_tape(ptg_env* h, uint64_t seed, int per_env_len, void* stream)
+{
+    if (!h || per_env_len <= 0) return set_err(h, PTG_E_INVALID, "bad noise tape length");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = set_tape_len(h, per_env_len);
+    if (rc) return rc;
+    const long long total = (long long)h->n * per_env_len;
+    hipLaunchKernelGGL(k_fill_noise, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), h->d_tape, h->n, per_env_len,
+                       (unsigned long long)seed, h->noise_epoch++, h->env_offset, h->cfg.noise);
+    if ((rc = launch_check(h, "k_fill_noise"))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->P.st_nctr, 0, sizeof(int) * h->n, as_stream(stream)));
+    return 0;
+}
+
+int ptg_get_noise_tape(ptg_env* h, double* tape_host)
+{
+    if (!h || !tape_host) return set_err(h, PTG_E_INVALID, "null argument");
+    if (h->tape_len <= 0) return set_err(h, PTG_E_INVALID, "no noise tape set");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(tape_host, h->d_tape, sizeof(double) * (size_t)h->n * h->tape_len, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ptg_reset(ptg_env* h, const uint8_t* mask_host, void* obs_dev, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    uint8_t* d_mask = nullptr;
+    if (mask_host) {
+        HIP_TRY(h, hipMalloc((void**)&d_mask, h->n));
+        HIP_TRY(h, hipMemcpyAsync(d_mask, mask_host, h->n, hipMemcpyHostToDevice, st));
+    }
+    if (h->cfg.out_dtype == PTG_OUT_F64)
+        hipLaunchKernelGGL(k_reset<double>, dim3(grid_for(h->n, 256)), dim3(256), 0, st, h->P, d_mask, (double*)obs_dev);
+    else
+        hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(h->n, 256)), dim3(256), 0, st, h->P, d_mask, (float*)obs_dev);
+    int rc = launch_check(h, "k_reset");
+    if (d_mask) { (void)hipStreamSynchronize(st); (void)hipFree(d_mask); }
+    if (rc) return rc;
+    if (!mask_host) h->reset_done = true;
+    return 0;
+}
+
+int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev, uint8_t* done_dev,
+             void* final_obs_dev, double* info_dev, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!actions_dev || !obs_dev || !rew_dev || !done_dev) return set_err(h, PTG_E_INVALID, "ptg_step: null buffer");
+    if (action_kind < PTG_ACT_I32 || action_kind > PTG_ACT_I64) return set_err(h, PTG_E_INVALID, "ptg_step: bad action_kind");
+    if ((h->cfg.action_type == 1) != (action_kind == PTG_ACT_F32))
+        return set_err(h, PTG_E_INVALID, "ptg_step: action_kind does not match cfg.action_type");
+    if (!h->reset_done) return set_err(h, PTG_E_INVALID, "ptg_step: envs must be reset first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(grid_for(h->n, 256)), block(256);
+    const bool f64 = h->cfg.out_dtype == PTG_OUT_F64;
+    if (info_dev) {
+        if (f64) hipLaunchKernelGGL((k_step<double, true>), grid, block, 0, st, h->P, actions_dev, action_kind, (double*)obs_dev,
+                                    (double*)rew_dev, done_dev, (double*)final_obs_dev, info_dev);
+        else hipLaunchKernelGGL((k_step<float, true>), grid, block, 0, st, h->P, actions_dev, action_kind, (float*)obs_dev,
+                                (float*)rew_dev, done_dev, (float*)final_obs_dev, info_dev);
+    } else {
+        if (f64) hipLaunchKernelGGL((k_step<double, false>), grid, block, 0, st, h->P, actions_dev, action_kind, (double*)obs_dev,
+                                    (double*)rew_dev, done_dev, (double*)final_obs_dev, nullptr);
+        else hipLaunchKernelGGL((k_step<float, false>), grid, block, 0, st, h->P, actions_dev, action_kind, (float*)obs_dev,
+                                (float*)rew_dev, done_dev, (float*)final_obs_dev, nullptr);
+    }
+    return launch_check(h, "k_step");
+}
+
+int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
+                uint8_t* done_dev, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!actions_dev || !obs_dev || !rew_dev || !done_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "ptg_rollout: bad argument");
+    if (action_kind < PTG_ACT_I32 || action_kind > PTG_ACT_I64) return set_err(h, PTG_E_INVALID, "ptg_rollout: bad action_kind");
+    if ((h->cfg.action_type == 1) != (action_kind == PTG_ACT_F32))
+        return set_err(h, PTG_E_INVALID, "ptg_rollout: action_kind does not match cfg.action_type");
+    if (!h->reset_done) return set_err(h, PTG_E_INVALID, "ptg_rollout: envs must be reset first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(grid_for(h->n, 256)), block(256);
+    if (h->cfg.out_dtype == PTG_OUT_F64)
+        hipLaunchKernelGGL(k_rollout<double>, grid, block, 0, st, h->P, actions_dev, action_kind, n_steps, (double*)obs_dev,
+                           (double*)rew_dev, done_dev);
+    else
+        hipLaunchKernelGGL(k_rollout<float>, grid, block, 0, st, h->P, actions_dev, action_kind, n_steps, (float*)obs_dev,
+                           (float*)rew_dev, done_dev);
+    return launch_check(h, "k_rollout");
+}
+
+int ptg_sync(ptg_env* h, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return collect_error(h, as_stream(stream));
+}
+
+int ptg_get_state(ptg_env* h, int field, void* out_host)
+{
+    if (!h || !out_host) return set_err(h, PTG_E_INVALID, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int n = h->n;
+    const DevParams& P = h->P;
+    auto copy_i = [&](const int* src) -> int {
+        HIP_TRY(h, hipMemcpy(out_host, src, sizeof(int) * n, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    switch (field) {
+    case PTG_F_I: return copy_i(P.st_i);
+    case PTG_F_J: return copy_i(P.st_j);
+    case PTG_F_K: return copy_i(P.st_k);
+    case PTG_F_ACT_EP_D: return copy_i(P.st_actd);
+    case PTG_F_EP_PTR: return copy_i(P.st_epp);
+    case PTG_F_NOISE_COUNT: return copy_i(P.st_nctr);
+    case PTG_F_N_STATE_CHANGES: return copy_i(P.st_nchg);
+    case PTG_F_CUM_REW:
+        HIP_TRY(h, hipMemcpy(out_host, P.st_cum, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return 0;
+    default: break;
+    }
+    std::vector<unsigned> fl(n);
+    HIP_TRY(h, hipMemcpy(fl.data(), P.st_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    int* oi = (int*)out_host;
+    double* od = (double*)out_host;
+    for (int e = 0; e < n; e++) {
+        const unsigned f = fl[e];
+        const int pp = (f >> 6) & 7, fq = (f >> 9) & 7;
+        switch (field) {
+        case PTG_F_METH_STATE: oi[e] = f & 7; break;
+        case PTG_F_HOT_COLD: oi[e] = (f >> 3) & 1; break;
+        case PTG_F_STANDBY_TID: oi[e] = ((f >> 4) & 1) ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN; break;
+        case PTG_F_STARTUP_TID: oi[e] = ((f >> 5) & 1) ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD; break;
+        case PTG_F_PARTIAL_TID: oi[e] = pp == 0 ? PTG_T_OP1_START_P : 7 + pp; break;
+        case PTG_F_FULL_TID: oi[e] = fq == 0 ? PTG_T_OP2_START_F : (fq == 1 ? PTG_T_OP3_P_F : 11 + fq); break;
+        case PTG_F_CURRENT_ACTION: oi[e] = (f >> 12) & 7; break;
+        case PTG_F_MARKET_SET: oi[e] = (f >> 15) & 3; break;
+        case PTG_F_T_CAT: od[e] = h->Tvals[std::min<size_t>(f >> 17, h->Tvals.size() - 1)]; break;
+        default: return set_err(h, PTG_E_INVALID, "unknown state field %d", field);
+        }
+    }
+    return 0;
+}
+
+int ptg_set_state(ptg_env* h, int field, const void* in_host)
+{
+    if (!h || !in_host) return set_err(h, PTG_E_INVALID, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int n = h->n;
+    DevParams& P = h->P;
+    auto copy_i = [&](int* dst) -> int {
+        HIP_TRY(h, hipMemcpy(dst, in_host, sizeof(int) * n, hipMemcpyHostToDevice));
+        return 0;
+    };
+    switch (field) {
+    case PTG_F_I: return copy_i(P.st_i);
+    case PTG_F_J: return copy_i(P.st_j);
+    case PTG_F_K: return copy_i(P.st_k);
+    case PTG_F_ACT_EP_D: return copy_i(P.st_actd);
+    case PTG_F_EP_PTR: return copy_i(P.st_epp);
+    case PTG_F_NOISE_COUNT: return copy_i(P.st_nctr);
+    case PTG_F_N_STATE_CHANGES: return copy_i(P.st_nchg);
+    case PTG_F_CUM_REW:
+        HIP_TRY(h, hipMemcpy(P.st_cum, in_host, sizeof(double) * n, hipMemcpyHostToDevice));
+        return 0;
+    default: break;
+    }
+    std::vector<unsigned> fl(n);
+    HIP_TRY(h, hipMemcpy(fl.data(), P.st_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    const int* ii = (const int*)in_host;
+    const double* id = (const double*)in_host;
+    auto put = [](unsigned f, int shift, unsigned mask, unsigned v) { return (f & ~(mask << shift)) | ((v & mask) << shift); };
+    for (int e = 0; e < n; e++) {
+        unsigned f = fl[e];
+        switch (field) {
+        case PTG_F_METH_STATE: if (ii[e] < 0 || ii[e] > 4) return set_err(h, PTG_E_INVALID, "bad meth_state"); f = put(f, 0, 7, ii[e]); break;
+        case PTG_F_HOT_COLD: f = put(f, 3, 1, ii[e] != 0); break;
+        case PTG_F_STANDBY_TID: f = put(f, 4, 1, ii[e] == PTG_T_STANDBY_UP); break;
+        case PTG_F_STARTUP_TID: f = put(f, 5, 1, ii[e] == PTG_T_STARTUP_HOT); break;
+        case PTG_F_PARTIAL_TID: {
+            int t = ii[e];
+            if (t != PTG_T_OP1_START_P && (t < PTG_T_OP4_P_F_P_5 || t > PTG_T_OP8_F_P)) return set_err(h, PTG_E_INVALID, "bad partial table id");
+            f = put(f, 6, 7, t == PTG_T_OP1_START_P ? 0 : t - 7); break;
+        }
+        case PTG_F_FULL_TID: {
+            int t = ii[e];
+            if (t != PTG_T_OP2_START_F && t != PTG_T_OP3_P_F && (t < PTG_T_OP9_F_P_F_5 || t > PTG_T_OP12_F_P_F_20)) return set_err(h, PTG_E_INVALID, "bad full table id");
+            f = put(f, 9, 7, t == PTG_T_OP2_START_F ? 0 : (t == PTG_T_OP3_P_F ? 1 : t - 11)); break;
+        }
+        case PTG_F_CURRENT_ACTION: if (ii[e] < 0 || ii[e] > 4) return set_err(h, PTG_E_INVALID, "bad action"); f = put(f, 12, 7, ii[e]); break;
+        case PTG_F_MARKET_SET: if (ii[e] < 0 || ii[e] >= h->n_sets) return set_err(h, PTG_E_INVALID, "bad market set"); f = put(f, 15, 3, ii[e]); break;
+        case PTG_F_T_CAT: {
+            auto it = std::lower_bound(h->Tvals.begin(), h->Tvals.end(), id[e]);
+            if (it == h->Tvals.end() || *it != id[e]) return set_err(h, PTG_E_INVALID, "T_cat %.17g of env %d is not a table temperature", id[e], e);
+            f = (f & 0x1FFFFu) | ((unsigned)(it - h->Tvals.begin()) << 17); break;
+        }
+        default: return set_err(h, PTG_E_INVALID, "unknown state field %d", field);
+        }
+        fl[e] = f;
+    }
+    HIP_TRY(h, hipMemcpy(P.st_flags, fl.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_host, int32_t* env_ids_host, int cap, int* count)
+{
+    if (!h || !count || cap < 0) return set_err(h, PTG_E_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    int total = 0;
+    HIP_TRY(h, hipMemcpy(&total, h->P.fin_count, sizeof(int), hipMemcpyDeviceToHost));
+    const int have = std::min(total, h->P.fin_cap);
+    const int n = std::min(have, cap);
+    // entries [total - have, total) are live (ring); hand out the oldest n of them
+    std::vector<double> r(h->P.fin_cap); std::vector<int> l(h->P.fin_cap), id(h->P.fin_cap);
+    if (n > 0) {
+        HIP_TRY(h, hipMemcpy(r.data(), h->P.fin_ret, sizeof(double) * h->P.fin_cap, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(l.data(), h->P.fin_len, sizeof(int) * h->P.fin_cap, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(id.data(), h->P.fin_env, sizeof(int) * h->P.fin_cap, hipMemcpyDeviceToHost));
+        for (int q = 0; q < n; q++) {
+            const int slot = (total - have + q) % h->P.fin_cap;
+            if (returns_host) returns_host[q] = r[slot];
+            if (lengths_host) lengths_host[q] = l[slot];
+            if (env_ids_host) env_ids_host[q] = id[slot];
+        }
+    }
+    HIP_TRY(h, hipMemset(h->P.fin_count, 0, sizeof(int)));
+    *count = n;
+    return 0;
+}
+
+int ptg_debug_get_index_lut(ptg_env* h, double* T_values_host, int32_t* lut_host, int* n_T)
+{
+    if (!h || !n_T) return set_err(h, PTG_E_INVALID, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    *n_T = (int)h->Tvals.size();
+    if (T_values_host) memcpy(T_values_host, h->Tvals.data(), sizeof(double) * h->Tvals.size());
+    if (lut_host) HIP_TRY(h, hipMemcpy(lut_host, h->P.argidx, sizeof(int) * N_DEST * h->Tvals.size(), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ptg_debug_window_record(ptg_env* h, int table_id, int start_row, double* out7_host)
+{
+    if (!h || !out7_host || table_id < 0 || table_id >= NT) return set_err(h, PTG_E_INVALID, "bad argument");
+    if (start_row < 0 || start_row > h->tab_rows[table_id]) return set_err(h, PTG_E_INVALID, "start_row out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Rec r;
+    HIP_TRY(h, hipMemcpy(&r, h->P.rec + h->rec_base[table_id] + start_row, sizeof(Rec), hipMemcpyDeviceToHost));
+    out7_host[0] = r.T;
+    for (int c = 0; c < 5; c++) out7_host[1 + c] = r.m[c];
+    out7_host[6] = (double)r.tkey;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""HipEngine: the batched PtG env state on one MI355X, driven through the C ABI (include/ptg_env.h).
+
+PyTorch is plumbing here: it owns the observation / reward / done / action buffers (ROCm tensors whose
+data_ptr() is handed to the library) and the HIP stream; all env arithmetic runs in the hand-written
+kernels of csrc/ptg_env.hip.  There is no CPU path: constructing an engine without the extension or
+without a GPU raises.
+
+`consts` uses the key names of the reference's env kwargs (src/rl_utils.py:345-365) with the two strings
+already mapped to ints: raw_modified {0 raw, 1 mod}, action_type {0 discrete, 1 continuous},
+train_or_eval {0 train, 1 eval}.  `markets` is a list (one per business scenario in the batch) of dicts
+with el, pot_rew, part_full, gas, eua (1-D float64), scenario, rew_l_b, rew_u_b, r_0.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+TABLE_KEYS = ["startup_cold", "startup_hot", "cooldown", "standby_down", "standby_up",
+              "op1_start_p", "op2_start_f", "op3_p_f", "op4_p_f_p_5", "op5_p_f_p_10",
+              "op6_p_f_p_15", "op7_p_f_p_22", "op8_f_p", "op9_f_p_f_5", "op10_f_p_f_10",
+              "op11_f_p_f_15", "op12_f_p_f_20"]
+ACTIONS = ["standby", "cooldown", "startup", "partial_load", "full_load"]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class PtgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libptg_env error {code}: {msg}")
+        self.code = code
+
+
+class HipEngine:
+    def __init__(self, consts, tables, markets, n_envs, device=0, out_dtype="float32"):
+        import torch
+        self._torch = torch
+        self._L = _lib.lib()                      # raises if the extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); rl_ptg_amd has no CPU path")
+        self.n = int(n_envs)
+        self.device = torch.device("cuda", int(device))
+        self.out_dtype = {"float32": torch.float32, "float64": torch.float64}[out_dtype]
+        cfg = _lib.PtgConfig()
+        c = dict(consts)
+        c.setdefault("t_cat_initial", 16.0)
+        c["out_dtype"] = _lib.OUT_F64 if out_dtype == "float64" else _lib.OUT_F32
+        c["reserved"] = 0
+        for k in _lib.CONFIG_KEYS:
+            setattr(cfg, k, c[k])
+        self.consts = c
+        self._keep = []
+        tb = _lib.PtgTables()
+        for t, k in enumerate(TABLE_KEYS):
+            a = np.ascontiguousarray(tables[k], dtype=np.float64)
+            if a.ndim != 2 or a.shape[1] != 7:
+                raise ValueError(f"table {k}: expected [rows, 7], got {a.shape}")
+            self._keep.append(a)
+            tb.data_host[t] = _dp(a)
+            tb.rows[t] = a.shape[0]
+        if isinstance(markets, dict):
+            markets = [markets]
+        mk = (_lib.PtgMarket * len(markets))()
+        for s, m in enumerate(markets):
+            arrs = {k: np.ascontiguousarray(m[k], dtype=np.float64) for k in ("el", "pot_rew", "part_full", "gas", "eua")}
+            if not (len(arrs["el"]) == len(arrs["pot_rew"]) == len(arrs["part_full"])) or len(arrs["gas"]) != len(arrs["eua"]):
+                raise ValueError("market series lengths differ")
+            self._keep.extend(arrs.values())
+            mk[s].n_hours, mk[s].n_days = len(arrs["el"]), len(arrs["gas"])
+            mk[s].el_host, mk[s].pot_rew_host, mk[s].part_full_host = _dp(arrs["el"]), _dp(arrs["pot_rew"]), _dp(arrs["part_full"])
+            mk[s].gas_host, mk[s].eua_host = _dp(arrs["gas"]), _dp(arrs["eua"])
+            mk[s].scenario = int(m["scenario"])
+            mk[s].rew_l_b, mk[s].rew_u_b, mk[s].r_0 = float(m["rew_l_b"]), float(m["rew_u_b"]), float(m["r_0"])
+        self.n_sets = len(markets)
+        h = C.c_void_p()
+        rc = self._L.ptg_create(C.byref(cfg), C.byref(tb), mk, len(markets), self.n, int(device), C.byref(h))
+        if rc != 0:
+            raise PtgError(rc, self._L.ptg_last_error(None).decode())
+        self._h = h
+        self.obs_dim = self._L.ptg_obs_dim(h)
+        self.action_type = int(c["action_type"])
+        self.eval_mode = bool(c["train_or_eval"])
+        with torch.cuda.device(self.device):
+            self.obs = torch.zeros((self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
+            self.final_obs = torch.zeros((self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
+            self.rew = torch.zeros(self.n, dtype=self.out_dtype, device=self.device)
+            self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+            self.info = torch.zeros((self.n, _lib.N_INFO), dtype=torch.float64, device=self.device) if self.eval_mode else None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ptg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PtgError(rc, self._L.ptg_last_error(self._h).decode())
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _action_kind(self, t):
+        torch = self._torch
+        if t.dtype == torch.int32:
+            return _lib.ACT_I32
+        if t.dtype == torch.int64:
+            return _lib.ACT_I64
+        if t.dtype == torch.float32:
+            return _lib.ACT_F32
+        raise TypeError(f"actions must be int32 / int64 / float32, got {t.dtype}")
+
+    def as_device_actions(self, actions):
+        """numpy / torch actions -> contiguous device tensor of a dtype the kernels read."""
+        torch = self._torch
+        if not torch.is_tensor(actions):
+            a = np.asarray(actions)
+            a = a.astype(np.float32) if self.action_type == 1 else a.astype(np.int32)
+            actions = torch.from_numpy(np.ascontiguousarray(a))
+        if actions.device != self.device:
+            actions = actions.to(self.device, non_blocking=True)
+        if self.action_type == 1 and actions.dtype != torch.float32:
+            actions = actions.float()
+        return actions.contiguous()
+
+    # ------------------------------------------------------------------ configuration
+    def set_market_assignment(self, set_of_env):
+        a = np.ascontiguousarray(set_of_env, dtype=np.uint8)
+        assert a.shape == (self.n,)
+        self._chk(self._L.ptg_set_market_assignment(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def set_episode_plan(self, eps_ind, first_ptr, stride):
+        if eps_ind is None or len(eps_ind) == 0:
+            self._chk(self._L.ptg_set_episode_plan(self._h, None, 0, 0, 0))
+            return
+        a = np.ascontiguousarray(eps_ind, dtype=np.float64)
+        self._chk(self._L.ptg_set_episode_plan(self._h, _dp(a), len(a), int(first_ptr), int(stride)))
+
+    def set_noise_tape(self, tape):
+        if tape is None:
+            self._chk(self._L.ptg_set_noise_tape(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(tape, dtype=np.float64)
+        assert a.ndim == 2 and a.shape[0] == self.n
+        self._chk(self._L.ptg_set_noise_tape(self._h, _dp(a), a.shape[1]))
+
+    def fill_noise_tape(self, seed, per_env_len):
+        self._chk(self._L.ptg_fill_noise_tape(self._h, int(seed) & (2 ** 64 - 1), int(per_env_len), self._stream()))
+        self.tape_len = int(per_env_len)
+
+    def get_noise_tape(self, per_env_len):
+        out = np.zeros((self.n, per_env_len))
+        self._chk(self._L.ptg_get_noise_tape(self._h, _dp(out)))
+        return out
+
+    # ------------------------------------------------------------------ hot path
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert m.shape == (self.n,)
+        with self._torch.cuda.device(self.device):
+            self._chk(self._L.ptg_reset(self._h, None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                        C.c_void_p(self.obs.data_ptr()), self._stream()))
+        return self.obs
+
+    def step(self, actions, obs=None, rew=None, done=None, final_obs=None, want_final=True):
+        """Enqueue one vector step on the current stream; returns (obs, rew, done) device tensors (no sync)."""
+        a = self.as_device_actions(actions)
+        assert a.numel() == self.n
+        obs = self.obs if obs is None else obs
+        rew = self.rew if rew is None else rew
+        done = self.done if done is None else done
+        fo = (self.final_obs if final_obs is None else final_obs) if want_final else None
+        with self._torch.cuda.device(self.device):
+            self._chk(self._L.ptg_step(self._h, C.c_void_p(a.data_ptr()), self._action_kind(a), C.c_void_p(obs.data_ptr()),
+                                       C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                                       C.c_void_p(fo.data_ptr()) if fo is not None else None,
+                                       C.c_void_p(self.info.data_ptr()) if self.info is not None else None, self._stream()))
+        return obs, rew, done
+
+    def rollout(self, actions, obs=None, rew=None, done=None):
+        """T fused steps in one launch: actions [T, N] -> obs [T, N, F], rew [T, N], done [T, N]."""
+        torch = self._torch
+        a = self.as_device_actions(actions)
+        assert a.dim() == 2 and a.shape[1] == self.n
+        T = a.shape[0]
+        with torch.cuda.device(self.device):
+            if obs is None:
+                obs = torch.empty((T, self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
+            if rew is None:
+                rew = torch.empty((T, self.n), dtype=self.out_dtype, device=self.device)
+            if done is None:
+                done = torch.empty((T, self.n), dtype=torch.uint8, device=self.device)
+            self._chk(self._L.ptg_rollout(self._h, C.c_void_p(a.data_ptr()), self._action_kind(a), T, C.c_void_p(obs.data_ptr()),
+                                          C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
+        return obs, rew, done
+
+    def sync(self):
+        self._chk(self._L.ptg_sync(self._h, self._stream()))
+
+    # ------------------------------------------------------------------ state access
+    def get_state(self, name):
+        f = _lib.STATE_FIELDS[name]
+        out = np.zeros(self.n, np.float64 if f >= 32 else np.int32)
+        self._chk(self._L.ptg_get_state(self._h, f, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def set_state(self, name, values):
+        f = _lib.STATE_FIELDS[name]
+        a = np.ascontiguousarray(values, dtype=np.float64 if f >= 32 else np.int32)
+        assert a.shape == (self.n,)
+        self._chk(self._L.ptg_set_state(self._h, f, C.c_void_p(a.ctypes.data)))
+
+    def finished_episodes(self, cap=None):
+        cap = 2 * self.n if cap is None else int(cap)
+        r = np.zeros(cap)
+        l = np.zeros(cap, np.int32)
+        ids = np.zeros(cap, np.int32)
+        cnt = C.c_int(0)
+        self._chk(self._L.ptg_finished_episodes(self._h, _dp(r), l.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                ids.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(cnt)))
+        n = cnt.value
+        return r[:n], l[:n], ids[:n]
+
+    def debug_get_index_lut(self):
+        nT = C.c_int(0)
+        self._chk(self._L.ptg_debug_get_index_lut(self._h, None, None, C.byref(nT)))
+        T = np.zeros(nT.value)
+        lut = np.zeros((6, nT.value), np.int32)
+        self._chk(self._L.ptg_debug_get_index_lut(self._h, _dp(T), lut.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nT)))
+        return T, lut
+
+    def debug_window_record(self, table_id, start_row):
+        out = np.zeros(7)
+        self._chk(self._L.ptg_debug_window_record(self._h, int(table_id), int(start_row), _dp(out)))
+        return out

@@ -53,3 +53,23 @@ def make_oracle(case):
     env = po.OracleVecEnv(consts, tables, market, tr["meta"]["n_envs"], ep_index0=tr["meta"]["ep_index0"])
     env.set_noise_tape(tr["noise"])
     return tr, env
+
+
+def market_for_engine(consts, market, prep_meta=None):
+    """oracle-style market dict -> HipEngine market dict (adds the scenario-dependent scalars)."""
+    m = {k: market[k] for k in ("el", "pot_rew", "part_full", "gas", "eua")}
+    m.update(scenario=consts["scenario"], rew_l_b=consts["rew_l_b"], rew_u_b=consts["rew_u_b"], r_0=consts["r_0"])
+    return m
+
+
+def make_engine(case, out_dtype="float64", n_envs=None):
+    """HIP engine on cuda:0 configured exactly like the reference run that produced the fixture."""
+    from rl_ptg_amd.engine import HipEngine
+    tr, consts, tables, market = load_traj(case)
+    n = tr["meta"]["n_envs"] if n_envs is None else n_envs
+    eng = HipEngine(consts, tables, market_for_engine(consts, market), n, device=0, out_dtype=out_dtype)
+    eng.set_noise_tape(tr["noise"])
+    if market["eps_ind"] is not None:
+        # DummyVecEnv order: n constructions consume eps_ind[0:n], the first vector reset takes eps_ind[n + e]
+        eng.set_episode_plan(market["eps_ind"], first_ptr=n, stride=n)
+    return tr, eng

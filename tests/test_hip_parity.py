@@ -1,0 +1,159 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors of the unmodified reference and
+against the CPU oracle.  Integers bit-exact; floats within the tolerances written below (north_star: 1e-5
+relative; measured margins are far tighter)."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+# float64 outputs: identical operand order -> at most a few ulp (pow() vs multiply in the efficiency polynomial)
+RTOL64, ATOL64 = 1e-11, 1e-13
+# float32 outputs: one rounding of the float64 result
+RTOL32, ATOL32 = 2e-7, 1e-9
+
+INT_FIELDS = ["meth_state", "i", "j", "hot_cold", "standby_tid", "startup_tid", "partial_tid", "full_tid", "k", "current_action"]
+
+
+def _ints(eng):
+    cols = [eng.get_state(f) for f in INT_FIELDS]
+    actd = eng.get_state("act_ep_d")
+    return np.stack(cols + [actd * 24, actd], axis=1)
+
+
+@pytest.mark.parametrize("out_dtype", ["float64", "float32"])
+@pytest.mark.parametrize("case", H.TRAJ_CASES)
+def test_trajectory_vs_reference_golden(case, out_dtype):
+    tr, eng = H.make_engine(case, out_dtype)
+    rtol, atol = (RTOL64, ATOL64) if out_dtype == "float64" else (RTOL32, ATOL32)
+    K, n = tr["actions"].shape
+    obs0 = eng.reset().cpu().numpy()
+    np.testing.assert_allclose(obs0, tr["reset_obs"], rtol=rtol, atol=atol)
+    assert np.array_equal(_ints(eng), tr["reset_int"])
+    post_at = [tuple(x) for x in tr["post_reset_at"].tolist()]
+    n_post = 0
+    check_every = 1 if K <= 1000 else 7
+    ret_acc = np.zeros(n)
+    fin_expect, fin_got = [], []
+    for t in range(K):
+        obs, rew, done = eng.step(tr["actions"][t])
+        eng.sync()
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        assert np.array_equal(done, tr["done"][t]), f"done differs at step {t}"
+        np.testing.assert_allclose(rew, tr["f64s"][t, :, 0], rtol=rtol, atol=atol, err_msg=f"reward, step {t}")
+        ret_acc += tr["f64s"][t, :, 0]
+        final = eng.final_obs.cpu().numpy()
+        any_done = bool(done.any())
+        if any_done or t % check_every == 0 or t == K - 1:
+            ints = _ints(eng)
+            T = eng.get_state("T_cat")
+            cum = eng.get_state("cum_rew")
+        for e in range(n):
+            if done[e]:
+                assert post_at[n_post] == (t, e)
+                np.testing.assert_allclose(final[e], tr["obs"][t, e], rtol=rtol, atol=atol)
+                np.testing.assert_allclose(obs[e], tr["post_reset_obs"][n_post], rtol=rtol, atol=atol)
+                assert np.array_equal(ints[e], tr["post_reset_int"][n_post])
+                fin_expect.append((e, ret_acc[e], int(tr["ints"][t, e, 8])))
+                ret_acc[e] = 0.0
+                n_post += 1
+            else:
+                np.testing.assert_allclose(obs[e], tr["obs"][t, e], rtol=rtol, atol=atol, err_msg=f"obs, step {t} env {e}")
+                if any_done or t % check_every == 0 or t == K - 1:
+                    assert np.array_equal(ints[e], tr["ints"][t, e]), f"int state, step {t} env {e}: {ints[e]} vs {tr['ints'][t, e]}"
+                    assert T[e] == tr["f64s"][t, e, 2]
+                    np.testing.assert_allclose(cum[e], tr["f64s"][t, e, 1], rtol=1e-11, atol=1e-9)
+        if any_done:
+            r, l, ids = eng.finished_episodes()
+            fin_got.extend(zip(ids.tolist(), l.tolist(), r.tolist()))
+        if "infos" in tr:
+            info = eng.info.cpu().numpy()
+            np.testing.assert_allclose(info, tr["infos"][t], rtol=RTOL64, atol=ATOL64, err_msg=f"info rows, step {t}")
+    assert n_post == len(post_at)
+    assert np.array_equal(eng.get_state("noise_count"), tr["noise_len"])
+    r, l, ids = eng.finished_episodes()
+    assert len(r) == 0
+    assert len(fin_got) == len(fin_expect)
+    got = sorted(fin_got)
+    exp = sorted((e, ln, rr) for e, rr, ln in fin_expect)
+    for (e1, l1, r1), (e2, l2, r2) in zip(got, exp):
+        assert e1 == e2 and l1 == l2
+        assert abs(r1 - r2) <= 1e-9 * max(1.0, abs(r2))
+    eng.close()
+
+
+@pytest.mark.parametrize("op,case", [("OP1", "synth_bs1_op1_mod_disc_train"), ("OP2", "synth_bs2_op2_mod_disc_train")])
+def test_device_built_get_index_lut(op, case):
+    """k_build_argmin == the reference's _get_index for every distinct catalyst temperature."""
+    u = H.load_npz(f"{H.GOLD}/units_{op}.npz")
+    tr, eng = H.make_engine(case)
+    T, lut = eng.debug_get_index_lut()
+    assert np.array_equal(T, u["T"])
+    assert u["dests"].tolist() == ["cooldown", "standby_up", "standby_down", "startup_cold", "startup_hot", "op1_start_p"]
+    assert np.array_equal(lut, u["get_index"])
+    eng.close()
+
+
+@pytest.mark.parametrize("case", ["synth_bs2_op2_mod_disc_train", "synth_bs1_op1_s60_toggle"])
+def test_device_built_window_records_match_numpy_average(case):
+    """k_build_records == slicing + np.average (NumPy pairwise order), incl. table-end and splice windows."""
+    tr, eng = H.make_engine(case)
+    _, consts, tables, _ = H.load_traj(case)
+    S = consts["sim_step"] // consts["time_step_op"]
+    rng = np.random.default_rng(1)
+    for tid, key in enumerate(H.po.TABLE_KEYS):
+        tab = tables[key]
+        n = len(tab)
+        starts = sorted(set([0, 1, n - S - 1, n - S, n - S + 1, n - 1, n] + rng.integers(0, n, 6).tolist()))
+        for r in starts:
+            if r < 0:
+                continue
+            if r == n:
+                win = np.ones((S, 7)) * tab[-1]
+            elif r + S <= n:
+                win = tab[r:r + S]
+            elif tid <= 1:
+                win = np.concatenate((tab[r:], tables["op1_start_p"][:r + S - n]), axis=0)
+            else:
+                win = np.concatenate((tab[r:], np.ones((r + S - n, 7)) * tab[-1]), axis=0)
+            rec = eng.debug_window_record(tid, r)
+            assert rec[0] == win[-1, 1]
+            for c in range(5):
+                assert rec[1 + c] == np.average(win[:, 2 + c]), (key, r, c)
+    eng.close()
+
+
+@pytest.mark.parametrize("out_dtype", ["float64", "float32"])
+def test_rollout_equals_steps(out_dtype):
+    case = "synth_bs2_op2_term_penalty"
+    tr, e1 = H.make_engine(case, out_dtype)
+    _, e2 = H.make_engine(case, out_dtype)
+    K = 400
+    e1.reset(); e2.reset()
+    obs_r, rew_r, done_r = e2.rollout(tr["actions"][:K])
+    e2.sync()
+    for t in range(K):
+        o, r, d = e1.step(tr["actions"][t])
+        e1.sync()
+        assert np.array_equal(o.cpu().numpy(), obs_r[t].cpu().numpy())
+        assert np.array_equal(r.cpu().numpy(), rew_r[t].cpu().numpy())
+        assert np.array_equal(d.cpu().numpy(), done_r[t].cpu().numpy())
+    for f in INT_FIELDS + ["act_ep_d", "ep_ptr", "noise_count", "n_state_changes", "T_cat", "cum_rew"]:
+        assert np.array_equal(e1.get_state(f), e2.get_state(f)), f
+    e1.close(); e2.close()
+
+
+def test_invalid_discrete_action_is_an_error_not_ub():
+    from rl_ptg_amd.engine import PtgError
+    tr, eng = H.make_engine("synth_bs2_op2_mod_disc_train")
+    eng.reset()
+    bad = np.array([7, 0], dtype=np.int32)
+    eng.step(bad)
+    with pytest.raises(PtgError) as ei:
+        eng.sync()
+    assert ei.value.code == -3
+    eng.step(np.array([-1, 4], dtype=np.int32))      # python-style negative index is legal: actions[-1] = full_load
+    eng.sync()
+    assert eng.get_state("current_action").tolist()[0] == 4
+    eng.close()
