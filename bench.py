@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched PtG env step on MI355X (BASELINE.json metric), with roofline and CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  Weak scaling: every rank owns --envs (default 65 536) envs; no per-step communication;
+one all-gather of finished-episode returns closes the timed region.
+
+A "step" is one vector step of the hot path over the whole batch (N_envs env-steps per rank): `ptg_step` launches
+(default, the drop-in VecEnv path) or one fused `ptg_rollout` launch of K steps (--path rollout).  Actions, state,
+observations, rewards and done flags are resident in HBM; nothing crosses PCIe inside the timed region.
+Workload: BASELINE.json configs[2] -- N = 65 536 envs, BS1/OP1, synthetic 38-day trace (32-day episodes), 'mod'
+features, discrete sticky actions, device-RNG noise tape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy peak
+
+
+def algorithmic_bytes_per_env_step(obs_dim, out_bytes, path):
+    """Compulsory HBM bytes per env-step of the shipped SoA layout.  Process tables, price series and
+    the noise tape are cache-resident and not counted."""
+    action = 4                               # int32 action
+    state = 16 + 16                          # StA {i, j, k, flags} + StB {cum_rew f64, act_ep_d, n_changes}; StC {noise_ctr, ep_ptr}
+                                             # is touched on state changes / resets only and is not counted
+    out = obs_dim * out_bytes + out_bytes + 1    # obs row + reward + done
+    if path == "rollout":                    # state stays in registers between the steps of one launch
+        return action + out
+    return action + 2 * state + out
+
+
+def cpu_baseline(spec, n_envs=4096, n_steps=600, seed=7):
+    """Oracle (CPU restatement of the reference, oracle/ptg_oracle.c) timed on this host's cores: bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ptg_oracle as po
+    po.build()
+    m = spec.markets[0]
+    consts = dict(spec.consts, scenario=m["scenario"], rew_l_b=m["rew_l_b"], rew_u_b=m["rew_u_b"], r_0=m["r_0"])
+    # eps_ind=None (episode offset 0): the synthetic trace has one episode, and n_envs reference envs would exhaust eps_ind
+    market = dict(el=m["el"], pot_rew=m["pot_rew"], part_full=m["part_full"], gas=m["gas"], eua=m["eua"], eps_ind=None)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = po.OracleVecEnv(consts, spec.tables, market, n_envs, ep_index0=0)
+    rng = np.random.default_rng(seed)
+    env.set_noise_tape(rng.normal(0, consts["noise"], (n_envs, 256)))
+    env.reset()
+    cur = rng.integers(0, 5, n_envs)
+    tapes = []
+    for _ in range(n_steps):
+        sw = rng.random(n_envs) < 1 / 12.0
+        cur = np.where(sw, rng.integers(0, 5, n_envs), cur)
+        tapes.append(cur.astype(np.int32))
+    for t in range(5):
+        env.step(tapes[t], n_threads=cores)
+    t0 = time.perf_counter()
+    for t in range(5, n_steps):
+        env.step(tapes[t], n_threads=cores)
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n_envs * (n_steps - 5) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ptg_oracle.c (OpenMP over envs), {n_envs} envs x {n_steps - 5} steps of the same workload, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--path", choices=["step", "rollout"], default="step")
+    ap.add_argument("--scenario", type=int, default=1)
+    ap.add_argument("--operation", default="OP1")
+    ap.add_argument("--out-dtype", choices=["float32", "float64"], default="float32")
+    ap.add_argument("--obs-layout", choices=["row", "feature"], default="feature",
+                    help="observation matrix layout: feature-major [F][N] (coalesced SoA stores) or row-major [N][F]")
+    ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rl_ptg_amd import dist as ptg_dist
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    from rl_ptg_amd.synthetic import sticky_actions_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the env step has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    K, W, n = args.steps, args.warmup, args.envs
+    n_total = n * world
+    spec, _ = synthetic_spec(scenario=args.scenario, operation=args.operation, eps_len_d=32)
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
+    first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
+    eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
+    tape_len = min(max(K + W + 8, 64), 1024)
+    eng.fill_noise_tape(seed=20250614 + rank, per_env_len=tape_len)
+    actions = sticky_actions_device(K + W, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
+    eng.reset()
+
+    if args.path == "rollout":
+        F = eng.obs_dim
+        oshape = (max(K, W, 1), F, n) if args.obs_layout == "feature" else (max(K, W, 1), n, F)
+        obs_buf = torch.empty(oshape, dtype=eng.out_dtype, device=device)
+        rew_buf = torch.empty((max(K, W, 1), n), dtype=eng.out_dtype, device=device)
+        done_buf = torch.empty((max(K, W, 1), n), dtype=torch.uint8, device=device)
+
+    def run(t0, cnt):
+        if cnt <= 0:
+            return
+        if args.path == "rollout":
+            eng.rollout(actions[t0:t0 + cnt], obs_buf[:cnt], rew_buf[:cnt], done_buf[:cnt])
+        else:
+            for t in range(t0, t0 + cnt):
+                eng.step(actions[t], want_final=False)
+
+    run(0, W)
+    eng.sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    ev0.record()
+    run(W, K)
+    ev1.record()
+    r, l, _ = eng.finished_episodes()          # synchronises; episodic-return reduction (one all-gather, off the step path)
+    r_all, l_all = ptg_dist.all_gather_finished(r, l, device=device)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    eng.sync()
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        out_bytes = 4 if args.out_dtype == "float32" else 8
+        b_alg = algorithmic_bytes_per_env_step(eng.obs_dim, out_bytes, args.path)
+        launches = 1 if args.path == "rollout" else K
+        per_launch_s = dev_ms * 1e-3 / launches
+        bytes_per_launch = b_alg * n * (K if args.path == "rollout" else 1)
+        achieved = bytes_per_launch / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.path}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/sec at N=65536 envs; achieved HBM GB/s vs roofline",
+            "value": n_total * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={n} envs/GPU, BS{args.scenario}/{args.operation}, synthetic 38-day trace (32-day episodes), "
+                                   f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), device noise tape",
+                       "path": "ptg_step (one launch per vector step)" if args.path == "step" else "ptg_rollout (K steps fused in one launch)",
+                       "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype, "obs_dim": eng.obs_dim, "obs_layout": args.obs_layout,
+                       "parallelism": f"env-sharded x{world}, no per-step collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "kernel": "k_step" if args.path == "step" else "k_rollout",
+                         "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6,
+                         "launches_timed": launches},
+            "finished_episodes_gathered": int(len(r_all)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(spec)
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

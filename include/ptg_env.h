@@ -50,6 +50,10 @@ enum {
 
 enum { PTG_ACT_I32 = 0, PTG_ACT_F32 = 1, PTG_ACT_I64 = 2 };   /* element type of the action buffer */
 enum { PTG_OUT_F32 = 0, PTG_OUT_F64 = 1 };                    /* element type of obs / reward buffers */
+/* Observation matrix layout.  ROW_MAJOR [N][F] is what DummyVecEnv hands to SB3 (one row per env).  FEATURE_MAJOR [F][N]
+ * is the struct-of-arrays form the kernels write with fully coalesced stores (a wave writes 64 consecutive envs of one
+ * feature); its transpose view is the same [N][F] matrix, e.g. torch: obs.t(). Rollouts: [T][N][F] resp. [T][F][N]. */
+enum { PTG_OBS_ROW_MAJOR = 0, PTG_OBS_FEATURE_MAJOR = 1 };
 
 /* Constants of the env: the flat kwargs of Preprocessing.dict_env_kwargs (src/rl_utils.py:345-365), same names.
  * Replaces: the attribute set PTGEnv.__init__ copies from dict_input (env/ptg_gym_env.py:40). */
@@ -73,7 +77,7 @@ typedef struct ptg_config {
     double state_change_penalty;        /* :332 */
     double t_cat_initial;               /* 16 in the reference (:117) */
     int32_t out_dtype;                  /* PTG_OUT_F32 | PTG_OUT_F64 */
-    int32_t reserved;
+    int32_t obs_layout;                 /* PTG_OBS_ROW_MAJOR | PTG_OBS_FEATURE_MAJOR */
 } ptg_config;
 
 /* The 17 process tables (src/rl_utils.py:46-67): row-major [rows][7] = t, T_cat, n_h2, n_ch4, n_h2_res, m_h2o, P_el */
@@ -135,7 +139,8 @@ int ptg_get_noise_tape(ptg_env* env, double* tape_host);          /* [n_envs][pe
 int ptg_reset(ptg_env* env, const uint8_t* mask_host, void* obs_dev, void* stream);
 /* One vector step (:336-481) + DummyVecEnv auto-reset.
  *   actions_dev  [N]     int32 / float32 / int64 per action_kind (PTG_ACT_*)
- *   obs_dev      [N][F]  out_dtype; row of a finished env = observation after its reset
+ *   obs_dev      [N][F]  out_dtype ([F][N] when cfg.obs_layout is FEATURE_MAJOR; final_obs_dev alike);
+ *                        row of a finished env = observation after its reset
  *   rew_dev      [N]     out_dtype
  *   done_dev     [N]     uint8
  *   final_obs_dev[N][F]  (nullable) rows of finished envs = terminal observation

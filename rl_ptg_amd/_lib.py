@@ -14,6 +14,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 N_TABLES, N_INFO = 17, 24
 ACT_I32, ACT_F32, ACT_I64 = 0, 1, 2
 OUT_F32, OUT_F64 = 0, 1
+OBS_ROW_MAJOR, OBS_FEATURE_MAJOR = 0, 1
 
 _D1 = ["noise"]
 _I1 = ["eps_len_d", "sim_step", "time_step_op", "price_ahead"]
@@ -29,7 +30,7 @@ _D3 = ["el_l_b", "el_u_b", "gas_l_b", "gas_u_b", "eua_l_b", "eua_u_b", "T_l_b", 
        "ch4_l_b", "ch4_u_b", "h2_res_l_b", "h2_res_u_b", "h2o_l_b", "h2o_u_b", "heat_l_b", "heat_u_b"]
 _I3 = ["raw_modified", "action_type", "train_or_eval", "eps_sim_steps"]
 _D4 = ["state_change_penalty", "t_cat_initial"]
-_I4 = ["out_dtype", "reserved"]
+_I4 = ["out_dtype", "obs_layout"]
 CONFIG_KEYS = _D1 + _I1 + _D2 + _I2 + _D3 + _I3 + _D4 + _I4
 
 

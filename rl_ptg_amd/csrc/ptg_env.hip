@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -42,13 +43,26 @@ struct alignas(64) Rec {      // one window start: 64 B = half an L2 line, never
 };
 static_assert(sizeof(Rec) == 64, "Rec must be 64 bytes");
 
-struct Regs {                 // per-env mutable state, as held in registers
-    int i, j, k;
-    unsigned flags;           // [0:3) meth_state [3] hot_cold [4] standby=up [5] startup=hot [6:9) part_op [9:12) full_op
-                              // [12:15) current_action [15:17) market set [17:32) T key
-    int act_d;                // act_ep_d (:61,492); act_ep_h = 24 * act_d
-    int nctr, nchg, epp;      // noise draws consumed, state changes this episode, pointer into eps_ind
-    double cum;               // cum_rew (:330)
+// Strength-reduced record of the float32 fast path.  The reward (:280-334) is linear in the three prices once the
+// window is fixed: rew = base + ch4*(b_s3*k_chp + k_eua*eua) + c_gas*gas - c_el*el, and the electrolyzer efficiency
+// polynomial (:311-317) depends on the window only -- so k_build_fast evaluates it once per window start.
+struct alignas(64) RecFast {
+    double base, ch4, c_gas, c_el;   // all pre-multiplied by sim_step/3600 except ch4 (raw mean methane flow)
+    float feat[6];                   // normalised T_cat, H2, CH4, H2_res, H2O, el_heating (:212-217)
+    int tkey;
+    int pad;
+};
+static_assert(sizeof(RecFast) == 64, "RecFast must be 64 bytes");
+
+// Per-env state, three arrays of naturally aligned structs (16-B / 16-B / 8-B lanes -> dwordx4 / dwordx2 accesses)
+struct alignas(16) StA { int i, j, k; unsigned flags; };   // flags: [0:3) meth_state [3] hot_cold [4] standby=up [5] startup=hot
+                                                            // [6:9) part_op [9:12) full_op [12:15) current_action [15:17) market set [17:32) T key
+struct alignas(16) StB { double cum; int act_d; int nchg; };   // cum_rew (:330), act_ep_d (:61,492), state changes this episode
+struct alignas(8) StC { int nctr; int epp; };                  // noise draws consumed, pointer into eps_ind (touched on transitions / resets only)
+
+struct Regs {
+    StA a; StB b; StC c;
+    bool c_loaded, c_dirty;
 };
 
 struct DevParams {
@@ -63,22 +77,24 @@ struct DevParams {
            rho, water_price, min_load, max_h2, c_m2, c_m3, sim_step_d;
     double T_lo, T_rng, h2_lo, h2_rng, ch4_lo, ch4_rng, h2r_lo, h2r_rng, h2o_lo, h2o_rng, heat_lo, heat_rng;
     double reset_flow[5], T_init;
+    double k_chp, k_eua;                   // fast path: per-unit-CH4 CHP revenue and EUA revenue factors (x sim_step/3600)
     // tables
     const Rec* rec;
+    const RecFast* recf;
     const int2* tabmeta;                   // [17] {rows, record base}
     const int* argidx;                     // [6][nT]
     const double* Tvals;                   // [nT]
     const double* tape;                    // [N][tape_len]
     const int* eps_ind;                    // [E]
     const double2* sincos;                 // [eps_sim_steps + 1]
+    const float2* sincos32;
     // market, [set][...] with strides hstride / dstride
     const double *el, *featA, *featB, *gas, *eua, *gas_n, *eua_n;
+    const float *featA32, *featB32, *gas_n32, *eua_n32;
     const double *pot_raw, *pf_raw;        // un-normalised pot_rew / part_full for info rows
     const double2* setc;                   // [sets] {b_s3, r_0 * state_change_penalty}
-    // state (SoA)
-    int *st_i, *st_j, *st_k, *st_actd, *st_nctr, *st_nchg, *st_epp;
-    unsigned* st_flags;
-    double* st_cum;
+    // state
+    StA* st_a; StB* st_b; StC* st_c;
     // finished-episode list
     double* fin_ret; int* fin_len; int* fin_env; int* fin_count; int fin_cap;
     int* err;
@@ -193,13 +209,17 @@ __global__ void k_fill_noise(double* __restrict__ tape, int N, int L, unsigned l
 // ------------------------------------------------------------------------------------------------ the env step
 __device__ __forceinline__ void load_regs(const DevParams& P, int e, Regs& R)
 {
-    R.i = P.st_i[e]; R.j = P.st_j[e]; R.k = P.st_k[e]; R.flags = P.st_flags[e]; R.act_d = P.st_actd[e];
-    R.nctr = P.st_nctr[e]; R.nchg = P.st_nchg[e]; R.epp = P.st_epp[e]; R.cum = P.st_cum[e];
+    R.a = P.st_a[e]; R.b = P.st_b[e];
+    R.c_loaded = false; R.c_dirty = false;
+}
+__device__ __forceinline__ void need_c(const DevParams& P, int e, Regs& R)
+{
+    if (!R.c_loaded) { R.c = P.st_c[e]; R.c_loaded = true; }
 }
 __device__ __forceinline__ void store_regs(const DevParams& P, int e, const Regs& R)
 {
-    P.st_i[e] = R.i; P.st_j[e] = R.j; P.st_k[e] = R.k; P.st_flags[e] = R.flags; P.st_actd[e] = R.act_d;
-    P.st_nctr[e] = R.nctr; P.st_nchg[e] = R.nchg; P.st_epp[e] = R.epp; P.st_cum[e] = R.cum;
+    P.st_a[e] = R.a; P.st_b[e] = R.b;
+    if (R.c_dirty) P.st_c[e] = R.c;
 }
 
 // :346-357 -> action id 0..4, or -1 for an invalid discrete action
@@ -225,16 +245,16 @@ __device__ __forceinline__ int decode_action(const void* actions, int kind, size
 // Integer state machine of step() (:339-440) and _perform_sim_step (:525-557).  Returns the record index.
 __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, int e, bool& changed)
 {
-    unsigned f = R.flags;
+    unsigned f = R.a.flags;
     int s = f & 7, hot = (f >> 3) & 1, sb = (f >> 4) & 1, su = (f >> 5) & 1, pp = (f >> 6) & 7, fq = (f >> 9) & 7;
     const unsigned mset = (f >> 15) & 3;
-    int tkey = (int)(f >> 17);
+    const int tkey = (int)(f >> 17);
     // :339-342 hot/cold hysteresis on the previous catalyst temperature
     if (tkey <= P.key_cold_max) hot = 0;
     else if (tkey >= P.key_hot_min) hot = 1;
     const int prev = s;
     const int S = P.S;
-    int i = R.i, j = R.j, table;
+    int i = R.a.i, j = R.a.j, table;
     // :368-440 dispatch
     int kind;   // 0 continue, 1 _standby, 2 _cooldown, 3 _startup, 4 _partial, 5 _full
     if (act == 0) kind = (s == 0) ? 0 : 1;
@@ -255,9 +275,10 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
         else if (kind == 2) { s = 1; table = PTG_T_COOLDOWN; dest = 0; }
         else { s = 2; pp = 0; fq = 0; su = hot; table = su ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD; dest = su ? 4 : 3; }
         const int idx = P.argidx[dest * P.nT + tkey];
+        need_c(P, e, R);
         double z = 0.0;
-        if (P.tape_len > 0) z = P.tape[(size_t)e * P.tape_len + (R.nctr % P.tape_len)];
-        R.nctr += 1;
+        if (P.tape_len > 0) z = P.tape[(size_t)e * P.tape_len + (R.c.nctr % P.tape_len)];
+        R.c.nctr += 1; R.c_dirty = true;
         double x = (double)idx + z;                        // int(max(idx + normal, 0)) (:584-585)
         if (0 > x) x = 0;
         i = (int)x;
@@ -312,72 +333,122 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
         }
     }
     changed = (prev != s);
-    R.i = i; R.j = j;
-    R.flags = (unsigned)s | (hot << 3) | (sb << 4) | (su << 5) | (pp << 6) | (fq << 9) | ((unsigned)act << 12) |
-              (mset << 15) | ((unsigned)tkey << 17);
+    R.a.i = i; R.a.j = j;
+    R.a.flags = (unsigned)s | (hot << 3) | (sb << 4) | (su << 5) | (pp << 6) | (fq << 9) | ((unsigned)act << 12) |
+                (mset << 15) | ((unsigned)tkey << 17);
     return tm.y + r;
 }
 
-template <typename OUT>
-__device__ __forceinline__ void write_price_features(const DevParams& P, OUT* row, unsigned mset, int H, int D)
-{
-    const size_t hb = (size_t)mset * P.hstride + H, db = (size_t)mset * P.dstride + D;
-    const int PA = P.PA;
-    if (P.mod) {          // Pot_Reward (normalised), Part_Full (:238-239)
-        for (int q = 0; q < PA; q++) row[q] = (OUT)P.featA[hb + q];
-        for (int q = 0; q < PA; q++) row[PA + q] = (OUT)P.featB[hb + q];
-    } else {              // Elec_Price, Gas_Price, EUA_Price (:223-225)
-        for (int q = 0; q < PA; q++) row[q] = (OUT)P.featA[hb + q];
-        row[PA] = (OUT)P.gas_n[db]; row[PA + 1] = (OUT)P.gas_n[db + 1];
-        row[PA + 2] = (OUT)P.eua_n[db]; row[PA + 3] = (OUT)P.eua_n[db + 1];
+// Observation matrix addressing: ROW_MAJOR row e = base + e*F (feature stride 1); FEATURE_MAJOR = base + e (stride N):
+// lanes of a wave are consecutive envs, so every feature store is one contiguous 256-B (f32) / 512-B (f64) segment.
+template <typename OUT, bool FM>
+struct ObsRow {
+    OUT* p; size_t stride;
+    __device__ __forceinline__ ObsRow(OUT* base, const DevParams& P, int e)
+        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.N : 1) {}
+    __device__ __forceinline__ void put(int q, OUT v) const { p[(size_t)q * stride] = v; }
+    __device__ __forceinline__ OUT get(int q) const { return p[(size_t)q * stride]; }
+    __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+};
+
+// The 2*PA (+4) market features of an observation row.  load() issues every read before the first store so that the
+// loads pipeline (PAC = 13 compile-time: fully unrolled into registers; PAC = 0: generic price_ahead, rolled loop).
+template <typename OUT, bool FAST, bool FM, int PAC>
+struct PriceFeatures {
+    typedef typename std::conditional<FAST, float, double>::type V;
+    V a[PAC > 0 ? PAC : 1], b[PAC > 0 ? PAC : 1], d[4];
+    size_t hb, db;
+    __device__ __forceinline__ void load(const DevParams& P, unsigned mset, int H, int D)
+    {
+        hb = (size_t)mset * P.hstride + H; db = (size_t)mset * P.dstride + D;
+        if (PAC > 0) {
+            const V* pa = FAST ? (const V*)P.featA32 : (const V*)P.featA;
+            const V* pb = FAST ? (const V*)P.featB32 : (const V*)P.featB;
+#pragma unroll
+            for (int q = 0; q < PAC; q++) a[q] = pa[hb + q];
+            if (P.mod) {
+#pragma unroll
+                for (int q = 0; q < PAC; q++) b[q] = pb[hb + q];
+            } else {
+                const V* pg = FAST ? (const V*)P.gas_n32 : (const V*)P.gas_n;
+                const V* pe = FAST ? (const V*)P.eua_n32 : (const V*)P.eua_n;
+                d[0] = pg[db]; d[1] = pg[db + 1]; d[2] = pe[db]; d[3] = pe[db + 1];
+            }
+        }
     }
-}
+    __device__ __forceinline__ void store(const DevParams& P, const ObsRow<OUT, FM>& row) const
+    {
+        if (PAC > 0) {
+#pragma unroll
+            for (int q = 0; q < PAC; q++) row.put(q, (OUT)a[q]);
+            if (P.mod) {          // Pot_Reward (normalised), Part_Full (:238-239)
+#pragma unroll
+                for (int q = 0; q < PAC; q++) row.put(PAC + q, (OUT)b[q]);
+            } else {              // Elec_Price, Gas_Price, EUA_Price (:223-225)
+#pragma unroll
+                for (int q = 0; q < 4; q++) row.put(PAC + q, (OUT)d[q]);
+            }
+        } else {
+            const int PA = P.PA;
+            const V* pa = FAST ? (const V*)P.featA32 : (const V*)P.featA;
+            const V* pb = FAST ? (const V*)P.featB32 : (const V*)P.featB;
+            for (int q = 0; q < PA; q++) row.put(q, (OUT)pa[hb + q]);
+            if (P.mod) {
+                for (int q = 0; q < PA; q++) row.put(PA + q, (OUT)pb[hb + q]);
+            } else {
+                const V* pg = FAST ? (const V*)P.gas_n32 : (const V*)P.gas_n;
+                const V* pe = FAST ? (const V*)P.eua_n32 : (const V*)P.eua_n;
+                row.put(PA, (OUT)pg[db]); row.put(PA + 1, (OUT)pg[db + 1]);
+                row.put(PA + 2, (OUT)pe[db]); row.put(PA + 3, (OUT)pe[db + 1]);
+            }
+        }
+    }
+};
 
 // reset() (:483-506): takes the env's next episode, _initialize_op_rew (:105-138), writes the observation row
-template <typename OUT>
-__device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, OUT* row)
+template <typename OUT, bool FAST, bool FM, int PAC>
+__device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, int e, const ObsRow<OUT, FM>& row)
 {
     if (P.E > 0) {
-        R.act_d = P.eps_ind[R.epp] * P.eps_len_d;
-        R.epp += P.ep_stride;
-        if (R.epp >= P.E) R.epp %= P.E;
+        need_c(P, e, R);
+        R.b.act_d = P.eps_ind[R.c.epp] * P.eps_len_d;
+        R.c.epp += P.ep_stride;
+        if (R.c.epp >= P.E) R.c.epp %= P.E;
+        R.c_dirty = true;
     } else {
-        R.act_d = 0;
+        R.b.act_d = 0;
     }
-    const unsigned keep = R.flags & ((7u << 12) | (3u << 15));       // current_action survives reset(); market set is fixed
-    R.flags = 1u | keep | ((unsigned)P.key_init << 17);              // cooldown, cold, standby_down, startup_cold, op1, op2
-    R.i = P.i_reset; R.j = 0; R.k = 0; R.cum = 0.0; R.nchg = 0;
+    const unsigned keep = R.a.flags & ((7u << 12) | (3u << 15));     // current_action survives reset(); market set is fixed
+    R.a.flags = 1u | keep | ((unsigned)P.key_init << 17);            // cooldown, cold, standby_down, startup_cold, op1, op2
+    R.a.i = P.i_reset; R.a.j = 0; R.a.k = 0; R.b.cum = 0.0; R.b.nchg = 0;
     if (row) {
-        const unsigned mset = (R.flags >> 15) & 3;
-        write_price_features<OUT>(P, row, mset, R.act_d * 24, R.act_d);
-        OUT* p = row + (P.mod ? 2 * P.PA : P.PA + 4);
-        p[0] = (OUT)1.0;
-        p[1] = (OUT)((P.T_init - P.T_lo) / P.T_rng);
-        p[2] = (OUT)((P.reset_flow[0] - P.h2_lo) / P.h2_rng);
-        p[3] = (OUT)((P.reset_flow[1] - P.ch4_lo) / P.ch4_rng);
-        p[4] = (OUT)((P.reset_flow[2] - P.h2r_lo) / P.h2r_rng);
-        p[5] = (OUT)((P.reset_flow[3] - P.h2o_lo) / P.h2o_rng);
-        p[6] = (OUT)((P.reset_flow[4] - P.heat_lo) / P.heat_rng);
-        p[7] = (OUT)0.0;      // sin(0)
-        p[8] = (OUT)1.0;      // cos(0)
+        const unsigned mset = (R.a.flags >> 15) & 3;
+        PriceFeatures<OUT, FAST, FM, PAC> pf;
+        pf.load(P, mset, R.b.act_d * 24, R.b.act_d);
+        pf.store(P, row);
+        const int o = P.mod ? 2 * P.PA : P.PA + 4;
+        row.put(o + 0, (OUT)1.0);
+        row.put(o + 1, (OUT)((P.T_init - P.T_lo) / P.T_rng));
+        row.put(o + 2, (OUT)((P.reset_flow[0] - P.h2_lo) / P.h2_rng));
+        row.put(o + 3, (OUT)((P.reset_flow[1] - P.ch4_lo) / P.ch4_rng));
+        row.put(o + 4, (OUT)((P.reset_flow[2] - P.h2r_lo) / P.h2r_rng));
+        row.put(o + 5, (OUT)((P.reset_flow[3] - P.h2o_lo) / P.h2o_rng));
+        row.put(o + 6, (OUT)((P.reset_flow[4] - P.heat_lo) / P.heat_rng));
+        row.put(o + 7, (OUT)0.0);     // sin(0)
+        row.put(o + 8, (OUT)1.0);     // cos(0)
     }
 }
 
-// One env step.  obs_row / final_row / info_row may be null.  Returns terminated.
-template <typename OUT, bool INFO>
-__device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int act, OUT* obs_row, OUT* rew_out,
+// One env step.  Returns terminated.
+template <typename OUT, bool FAST, bool INFO, bool FM, int PAC>
+__device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int act, const ObsRow<OUT, FM>& row, OUT* rew_out,
                                          double* info_row)
 {
-    bool changed;
-    const int ridx = step_ints(P, R, act, e, changed);
-    const Rec rec = P.rec[ridx];
-    R.flags = (R.flags & 0x1FFFFu) | ((unsigned)rec.tkey << 17);       // Meth_T_cat = op[-1, 1] (:452)
-    const unsigned mset = (R.flags >> 15) & 3;
-    const int s = R.flags & 7;
-    // :442-450 clock and price columns at time (k+1)*dt
-    const int k1 = R.k + 1;
+    // :442-450 clock and price columns at time (k+1)*dt -- independent of the state machine, so these loads go first
+    const unsigned mset = (R.a.flags >> 15) & 3;
+    const int k1 = R.a.k + 1;
     const int secs = k1 * P.sim_step;
-    int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
+    int H = R.b.act_d * 24 + secs / 3600, D = R.b.act_d + secs / 86400;
     if (H + P.PA > P.n_hours || D + 2 > P.n_days || H < 0 || D < 0) {
         atomicOr(P.err, 2);
         H = max(0, min(H, P.n_hours - P.PA)); D = max(0, min(D, P.n_days - 2));
@@ -385,68 +456,94 @@ __device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int
     const double el = P.el[(size_t)mset * P.hstride + H];
     const double gas = P.gas[(size_t)mset * P.dstride + D];
     const double eua = P.eua[(size_t)mset * P.dstride + D];
-    const double2 sc = P.sincos[k1 <= P.eps_sim_steps ? k1 : P.eps_sim_steps];
     const double2 setc = P.setc[mset];
-    const double H2 = rec.m[0], CH4 = rec.m[1], H2r = rec.m[2], H2O = rec.m[3], heat = rec.m[4];
-    // :280-334 reward, operand order of the reference
-    const double ch4_vol = CH4 * P.c_mol;
-    const double h2r_vol = H2r * P.c_mol;
-    const double Q_ch4 = ch4_vol * P.Hu_ch4 * 1000;
-    const double Q_h2r = h2r_vol * P.Hu_h2 * 1000;
-    const double ch4_rev = (Q_ch4 + Q_h2r) * gas;
-    const double power_chp = Q_ch4 * P.eta_chp * setc.x;
-    const double Q_chp = Q_ch4 * P.one_m_eta_chp * setc.x;
-    const double chp_rev = power_chp * P.eeg;
-    const double Q_steam = H2O * P.dt_cp_evap / 3600;
-    const double steam_rev = (Q_steam + Q_chp) * P.heat_price;
-    const double h2_vol = H2 * P.c_mol;
-    const double o2_vol = 0.5 * h2_vol * 3600;
-    const double o2_rev = o2_vol * P.o2_price;
-    const double co2 = CH4 * P.M_co2 / 1000;
-    const double eua_rev = co2 / 1000 * 3600 * eua * 100;
-    const double cost_heat = heat / 1000 * el;
-    const double load = h2_vol / P.max_h2;
-    double eta;
-    if (load < P.min_load) {
-        eta = 0.02;
+    const int kk = k1 <= P.eps_sim_steps ? k1 : P.eps_sim_steps;
+    const int o = P.mod ? 2 * P.PA : P.PA + 4;
+    PriceFeatures<OUT, FAST, FM, PAC> pf;
+    if (row) pf.load(P, mset, H, D);
+    bool changed;
+    const int ridx = step_ints(P, R, act, e, changed);
+    const int s = R.a.flags & 7;
+    double rew;
+    if (FAST) {
+        const RecFast rec = P.recf[ridx];
+        R.a.flags = (R.a.flags & 0x1FFFFu) | ((unsigned)rec.tkey << 17);   // Meth_T_cat = op[-1, 1] (:452)
+        rew = rec.base + rec.ch4 * (setc.x * P.k_chp + P.k_eua * eua) + rec.c_gas * gas - rec.c_el * el;
+        R.b.cum += rew;
+        if (changed) { rew -= setc.y; R.b.nchg += 1; }
+        *rew_out = (OUT)rew;
+        if (row) {
+            const float2 sc = P.sincos32[kk];
+            pf.store(P, row);
+            row.put(o + 0, (OUT)s);
+            for (int q = 0; q < 6; q++) row.put(o + 1 + q, (OUT)rec.feat[q]);
+            row.put(o + 7, (OUT)sc.x);
+            row.put(o + 8, (OUT)sc.y);
+        }
     } else {
-        const double l2 = load * load, inv = 1.0 / load;
-        eta = 0.598 - 0.325 * l2 + 0.218 * (l2 * load) + 0.01 * inv - P.c_m2 * (inv * inv) + P.c_m3 * (inv * inv * inv);
+        const Rec rec = P.rec[ridx];
+        R.a.flags = (R.a.flags & 0x1FFFFu) | ((unsigned)rec.tkey << 17);
+        const double2 sc = P.sincos[kk];
+        const double H2 = rec.m[0], CH4 = rec.m[1], H2r = rec.m[2], H2O = rec.m[3], heat = rec.m[4];
+        // :280-334 reward, operand order of the reference
+        const double ch4_vol = CH4 * P.c_mol;
+        const double h2r_vol = H2r * P.c_mol;
+        const double Q_ch4 = ch4_vol * P.Hu_ch4 * 1000;
+        const double Q_h2r = h2r_vol * P.Hu_h2 * 1000;
+        const double ch4_rev = (Q_ch4 + Q_h2r) * gas;
+        const double power_chp = Q_ch4 * P.eta_chp * setc.x;
+        const double Q_chp = Q_ch4 * P.one_m_eta_chp * setc.x;
+        const double chp_rev = power_chp * P.eeg;
+        const double Q_steam = H2O * P.dt_cp_evap / 3600;
+        const double steam_rev = (Q_steam + Q_chp) * P.heat_price;
+        const double h2_vol = H2 * P.c_mol;
+        const double o2_vol = 0.5 * h2_vol * 3600;
+        const double o2_rev = o2_vol * P.o2_price;
+        const double co2 = CH4 * P.M_co2 / 1000;
+        const double eua_rev = co2 / 1000 * 3600 * eua * 100;
+        const double cost_heat = heat / 1000 * el;
+        const double load = h2_vol / P.max_h2;
+        double eta;
+        if (load < P.min_load) {
+            eta = 0.02;
+        } else {
+            const double l2 = load * load, inv = 1.0 / load;
+            eta = 0.598 - 0.325 * l2 + 0.218 * (l2 * load) + 0.01 * inv - P.c_m2 * (inv * inv) + P.c_m3 * (inv * inv * inv);
+        }
+        const double cost_elz = h2_vol * P.Hu_h2 * 1000 / eta * el;
+        const double cost_el = cost_heat + cost_elz;
+        const double water_elz = H2 * P.M_h2o / 1000 * 3600;
+        const double cost_water = (H2O + water_elz) / P.rho * P.water_price;
+        rew = (ch4_rev + chp_rev + steam_rev + eua_rev + o2_rev - cost_el - cost_water) * P.sim_step_d / 3600;
+        R.b.cum += rew;
+        if (changed) { rew -= setc.y; R.b.nchg += 1; }
+        *rew_out = (OUT)rew;
+        // :206-217 + :219-249 observation row
+        if (row) {
+            pf.store(P, row);
+            row.put(o + 0, (OUT)s);
+            row.put(o + 1, (OUT)((rec.T - P.T_lo) / P.T_rng));
+            row.put(o + 2, (OUT)((H2 - P.h2_lo) / P.h2_rng));
+            row.put(o + 3, (OUT)((CH4 - P.ch4_lo) / P.ch4_rng));
+            row.put(o + 4, (OUT)((H2r - P.h2r_lo) / P.h2r_rng));
+            row.put(o + 5, (OUT)((H2O - P.h2o_lo) / P.h2o_rng));
+            row.put(o + 6, (OUT)((heat - P.heat_lo) / P.heat_rng));
+            row.put(o + 7, (OUT)sc.x);
+            row.put(o + 8, (OUT)sc.y);
+        }
+        if (INFO && info_row) {   // :251-278
+            const size_t hb = (size_t)mset * P.hstride + H;
+            info_row[0] = (double)R.a.k; info_row[1] = el; info_row[2] = gas; info_row[3] = eua;
+            info_row[4] = (double)s; info_row[5] = (double)act; info_row[6] = (double)((R.a.flags >> 3) & 1);
+            info_row[7] = rec.T; info_row[8] = H2; info_row[9] = CH4; info_row[10] = H2O; info_row[11] = heat;
+            info_row[12] = ch4_rev; info_row[13] = steam_rev; info_row[14] = o2_rev; info_row[15] = eua_rev;
+            info_row[16] = chp_rev; info_row[17] = -cost_heat; info_row[18] = -cost_elz; info_row[19] = -cost_water;
+            info_row[20] = rew; info_row[21] = R.b.cum;
+            info_row[22] = P.pot_raw[hb]; info_row[23] = P.pf_raw[hb];
+        }
     }
-    const double cost_elz = h2_vol * P.Hu_h2 * 1000 / eta * el;
-    const double cost_el = cost_heat + cost_elz;
-    const double water_elz = H2 * P.M_h2o / 1000 * 3600;
-    const double cost_water = (H2O + water_elz) / P.rho * P.water_price;
-    double rew = (ch4_rev + chp_rev + steam_rev + eua_rev + o2_rev - cost_el - cost_water) * P.sim_step_d / 3600;
-    R.cum += rew;
-    if (changed) { rew -= setc.y; R.nchg += 1; }
-    *rew_out = (OUT)rew;
-    // :206-217 + :219-249 observation row
-    if (obs_row) {
-        write_price_features<OUT>(P, obs_row, mset, H, D);
-        OUT* p = obs_row + (P.mod ? 2 * P.PA : P.PA + 4);
-        p[0] = (OUT)s;
-        p[1] = (OUT)((rec.T - P.T_lo) / P.T_rng);
-        p[2] = (OUT)((H2 - P.h2_lo) / P.h2_rng);
-        p[3] = (OUT)((CH4 - P.ch4_lo) / P.ch4_rng);
-        p[4] = (OUT)((H2r - P.h2r_lo) / P.h2r_rng);
-        p[5] = (OUT)((H2O - P.h2o_lo) / P.h2o_rng);
-        p[6] = (OUT)((heat - P.heat_lo) / P.heat_rng);
-        p[7] = (OUT)sc.x;
-        p[8] = (OUT)sc.y;
-    }
-    if (INFO && info_row) {   // :251-278
-        const size_t hb = (size_t)mset * P.hstride + H;
-        info_row[0] = (double)R.k; info_row[1] = el; info_row[2] = gas; info_row[3] = eua;
-        info_row[4] = (double)s; info_row[5] = (double)act; info_row[6] = (double)((R.flags >> 3) & 1);
-        info_row[7] = rec.T; info_row[8] = H2; info_row[9] = CH4; info_row[10] = H2O; info_row[11] = heat;
-        info_row[12] = ch4_rev; info_row[13] = steam_rev; info_row[14] = o2_rev; info_row[15] = eua_rev;
-        info_row[16] = chp_rev; info_row[17] = -cost_heat; info_row[18] = -cost_elz; info_row[19] = -cost_water;
-        info_row[20] = rew; info_row[21] = R.cum;
-        info_row[22] = P.pot_raw[hb]; info_row[23] = P.pf_raw[hb];
-    }
-    const bool term = (R.k == P.eps_sim_steps - 6);   // :508-511, tested before k += 1
-    R.k = k1;
+    const bool term = (R.a.k == P.eps_sim_steps - 6);   // :508-511, tested before k += 1
+    R.a.k = k1;
     return term;
 }
 
@@ -466,7 +563,7 @@ __device__ __forceinline__ void push_finished(const DevParams& P, bool done, int
     }
 }
 
-template <typename OUT, bool INFO>
+template <typename OUT, bool FAST, bool INFO, bool FM, int PAC>
 __global__ void __launch_bounds__(256)
 k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT* __restrict__ obs, OUT* __restrict__ rew,
        uint8_t* __restrict__ done, OUT* __restrict__ final_obs, double* __restrict__ info)
@@ -479,23 +576,26 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
     int len = 0;
     if (live) {
         load_regs(P, e, R);
-        const int act = decode_action(actions, action_kind, e, (R.flags >> 12) & 7);
+        const int act = decode_action(actions, action_kind, e, (R.a.flags >> 12) & 7);
         if (act < 0) {
             atomicOr(P.err, 1);
             rew[e] = (OUT)NAN;
             done[e] = 0;
         } else {
-            OUT* row = obs + (size_t)e * P.F;
+            const ObsRow<OUT, FM> row(obs, P, e);
             double* irow = (INFO && info) ? info + (size_t)e * PTG_N_INFO : nullptr;
             OUT r;
-            term = env_step<OUT, INFO>(P, R, e, act, row, &r, irow);
+            term = env_step<OUT, FAST, INFO, FM, PAC>(P, R, e, act, row, &r, irow);
             rew[e] = r;
             done[e] = term ? 1 : 0;
             if (term) {
-                if (final_obs) for (int q = 0; q < P.F; q++) final_obs[(size_t)e * P.F + q] = row[q];
-                ret = R.cum - (double)R.nchg * P.setc[(R.flags >> 15) & 3].y;
-                len = R.k;
-                reset_env<OUT>(P, R, row);
+                if (final_obs) {
+                    const ObsRow<OUT, FM> frow(final_obs, P, e);
+                    for (int q = 0; q < P.F; q++) frow.put(q, row.get(q));
+                }
+                ret = R.b.cum - (double)R.b.nchg * P.setc[(R.a.flags >> 15) & 3].y;
+                len = R.a.k;
+                reset_env<OUT, FAST, FM, PAC>(P, R, e, row);
             }
             store_regs(P, e, R);
         }
@@ -503,7 +603,7 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
     push_finished(P, live && term, e, ret, len);
 }
 
-template <typename OUT>
+template <typename OUT, bool FAST, bool FM, int PAC>
 __global__ void __launch_bounds__(256)
 k_rollout(const DevParams P, const void* __restrict__ actions, int action_kind, int T, OUT* __restrict__ obs,
           OUT* __restrict__ rew, uint8_t* __restrict__ done)
@@ -513,26 +613,27 @@ k_rollout(const DevParams P, const void* __restrict__ actions, int action_kind, 
     Regs R;
     if (live) load_regs(P, e, R);
     bool bad = false;
+    const size_t NF = (size_t)P.N * P.F;
     for (int t = 0; t < T; t++) {
         bool term = false;
         double ret = 0.0;
         int len = 0;
         if (live && !bad) {
             const size_t g = (size_t)t * P.N + e;
-            const int act = decode_action(actions, action_kind, g, (R.flags >> 12) & 7);
+            const int act = decode_action(actions, action_kind, g, (R.a.flags >> 12) & 7);
             if (act < 0) {
                 atomicOr(P.err, 1);
                 bad = true;
             } else {
-                OUT* row = obs + g * P.F;
+                const ObsRow<OUT, FM> row(obs + (size_t)t * NF, P, e);
                 OUT r;
-                term = env_step<OUT, false>(P, R, e, act, row, &r, nullptr);
+                term = env_step<OUT, FAST, false, FM, PAC>(P, R, e, act, row, &r, nullptr);
                 rew[g] = r;
                 done[g] = term ? 1 : 0;
                 if (term) {
-                    ret = R.cum - (double)R.nchg * P.setc[(R.flags >> 15) & 3].y;
-                    len = R.k;
-                    reset_env<OUT>(P, R, row);
+                    ret = R.b.cum - (double)R.b.nchg * P.setc[(R.a.flags >> 15) & 3].y;
+                    len = R.a.k;
+                    reset_env<OUT, FAST, FM, PAC>(P, R, e, row);
                 }
             }
         }
@@ -541,7 +642,7 @@ k_rollout(const DevParams P, const void* __restrict__ actions, int action_kind, 
     if (live) store_regs(P, e, R);
 }
 
-template <typename OUT>
+template <typename OUT, bool FAST, bool FM, int PAC>
 __global__ void k_reset(const DevParams P, const uint8_t* __restrict__ mask, OUT* __restrict__ obs)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,7 +650,7 @@ __global__ void k_reset(const DevParams P, const uint8_t* __restrict__ mask, OUT
     if (mask && !mask[e]) return;
     Regs R;
     load_regs(P, e, R);
-    reset_env<OUT>(P, R, obs ? obs + (size_t)e * P.F : nullptr);
+    reset_env<OUT, FAST, FM, PAC>(P, R, e, ObsRow<OUT, FM>(obs, P, e));
     store_regs(P, e, R);
 }
 
@@ -558,12 +659,58 @@ __global__ void k_init_state(const DevParams P, int first_ptr_mod, int have_plan
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.N) return;
     if (have_plan) {
-        P.st_epp[e] = P.E > 0 ? (int)(((long long)first_ptr_mod + e) % P.E) : 0;
+        P.st_c[e].epp = P.E > 0 ? (int)(((long long)first_ptr_mod + e) % P.E) : 0;
         return;
     }
-    P.st_i[e] = 0; P.st_j[e] = 0; P.st_k[e] = 0; P.st_actd[e] = 0; P.st_nctr[e] = 0; P.st_nchg[e] = 0; P.st_epp[e] = 0;
-    P.st_flags[e] = 1u | (1u << 12) | ((unsigned)P.key_init << 17);   // cooldown, current_action = 'cooldown' (:143)
-    P.st_cum[e] = 0.0;
+    StA a; a.i = 0; a.j = 0; a.k = 0;
+    a.flags = 1u | (1u << 12) | ((unsigned)P.key_init << 17);   // cooldown, current_action = 'cooldown' (:143)
+    StB b; b.cum = 0.0; b.act_d = 0; b.nchg = 0;
+    StC c; c.nctr = 0; c.epp = 0;
+    P.st_a[e] = a; P.st_b[e] = b; P.st_c[e] = c;
+}
+
+__global__ void k_zero_noise_count(const DevParams P)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < P.N) P.st_c[e].nctr = 0;
+}
+
+// fast-path records from the window records: reward coefficients (:280-334) and normalised features (:212-217)
+__global__ void k_build_fast(const DevParams P, const Rec* __restrict__ in, RecFast* __restrict__ out, int n)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const Rec rec = in[g];
+    const double H2 = rec.m[0], CH4 = rec.m[1], H2r = rec.m[2], H2O = rec.m[3], heat = rec.m[4];
+    const double f = P.sim_step_d / 3600;
+    const double Q_ch4 = CH4 * P.c_mol * P.Hu_ch4 * 1000;
+    const double Q_h2r = H2r * P.c_mol * P.Hu_h2 * 1000;
+    const double Q_steam = H2O * P.dt_cp_evap / 3600;
+    const double h2_vol = H2 * P.c_mol;
+    const double o2_rev = 0.5 * h2_vol * 3600 * P.o2_price;
+    const double load = h2_vol / P.max_h2;
+    double eta;
+    if (load < P.min_load) {
+        eta = 0.02;
+    } else {
+        const double l2 = load * load, inv = 1.0 / load;
+        eta = 0.598 - 0.325 * l2 + 0.218 * (l2 * load) + 0.01 * inv - P.c_m2 * (inv * inv) + P.c_m3 * (inv * inv * inv);
+    }
+    const double water = (H2O + H2 * P.M_h2o / 1000 * 3600) / P.rho * P.water_price;
+    RecFast o;
+    o.base = (Q_steam * P.heat_price + o2_rev - water) * f;
+    o.ch4 = CH4;
+    o.c_gas = (Q_ch4 + Q_h2r) * f;
+    o.c_el = (heat / 1000 + h2_vol * P.Hu_h2 * 1000 / eta) * f;
+    o.feat[0] = (float)((rec.T - P.T_lo) / P.T_rng);
+    o.feat[1] = (float)((H2 - P.h2_lo) / P.h2_rng);
+    o.feat[2] = (float)((CH4 - P.ch4_lo) / P.ch4_rng);
+    o.feat[3] = (float)((H2r - P.h2r_lo) / P.h2r_rng);
+    o.feat[4] = (float)((H2O - P.h2o_lo) / P.h2o_rng);
+    o.feat[5] = (float)((heat - P.heat_lo) / P.heat_rng);
+    o.tkey = rec.tkey;
+    o.pad = 0;
+    out[g] = o;
 }
 
 }  // namespace
@@ -577,6 +724,8 @@ struct ptg_env {
     std::vector<void*> allocs;
     std::vector<double> Tvals;
     std::vector<int> tab_rows, rec_base;
+    size_t rec_total = 0;
+    bool fast = false, fm = false;
     double* d_tape = nullptr;
     int tape_len = 0;
     unsigned noise_epoch = 0;
@@ -684,6 +833,7 @@ int build_tables(ptg_env* h, const ptg_tables* tb)
     int rc;
     if ((rc = dev_upload(h, &d_T, Tv.data(), Tv.size()))) return rc;
     Rec* d_rec; int* d_arg; int2* d_meta;
+    h->rec_total = rec_total;
     if ((rc = dev_alloc(h, &d_rec, rec_total))) return rc;
     if ((rc = dev_alloc(h, &d_arg, (size_t)N_DEST * nT))) return rc;
     std::vector<int2> meta(NT);
@@ -765,6 +915,15 @@ int build_market(ptg_env* h, const ptg_market* sets, int n_sets)
     if ((rc = dev_upload(h, &h->d_pot_raw, pot.data(), pot.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_pf_raw, pf.data(), pf.size()))) return rc;
     if ((rc = dev_upload(h, &d_setc, setc.data(), setc.size()))) return rc;
+    {   // float32 copies of the pre-normalised feature series for the fast path (one rounding of the float64 value)
+        std::vector<float> fa32(fa.begin(), fa.end()), fb32(fb.begin(), fb.end()), g32(gasn.begin(), gasn.end()), e32(euan.begin(), euan.end());
+        float *d_a, *d_b, *d_g, *d_e;
+        if ((rc = dev_upload(h, &d_a, fa32.data(), fa32.size()))) return rc;
+        if ((rc = dev_upload(h, &d_b, fb32.data(), fb32.size()))) return rc;
+        if ((rc = dev_upload(h, &d_g, g32.data(), g32.size()))) return rc;
+        if ((rc = dev_upload(h, &d_e, e32.data(), e32.size()))) return rc;
+        P.featA32 = d_a; P.featB32 = d_b; P.gas_n32 = d_g; P.eua_n32 = d_e;
+    }
     P.pot_raw = h->d_pot_raw; P.pf_raw = h->d_pf_raw;
     P.el = d_el; P.featA = d_fa; P.featB = d_fb; P.gas = d_gas; P.eua = d_eua; P.gas_n = d_gasn; P.eua_n = d_euan; P.setc = d_setc;
     P.n_hours = nh; P.n_days = nd; P.hstride = nh; P.dstride = nd;
@@ -815,6 +974,7 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     if (cfg->time_step_op <= 0 || cfg->sim_step <= 0 || cfg->price_ahead < 1 || cfg->price_ahead > 64)
         return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad sim_step / time_step_op / price_ahead");
     if (cfg->out_dtype != PTG_OUT_F32 && cfg->out_dtype != PTG_OUT_F64) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad out_dtype");
+    if (cfg->obs_layout != PTG_OBS_ROW_MAJOR && cfg->obs_layout != PTG_OBS_FEATURE_MAJOR) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad obs_layout");
     if (cfg->eps_sim_steps < 7) return set_err(nullptr, PTG_E_INVALID, "ptg_create: eps_sim_steps must be >= 7");
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -828,6 +988,8 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     h->cfg = *cfg; h->n = n_envs; h->device = device_id; h->n_sets = n_sets;
     h->S = (int)((double)cfg->sim_step / (double)cfg->time_step_op);     // :66
     h->F = cfg->raw_modified ? 2 * cfg->price_ahead + 9 : cfg->price_ahead + 4 + 9;
+    h->fast = (cfg->out_dtype == PTG_OUT_F32);          // float32 outputs without info rows run the strength-reduced kernels
+    h->fm = (cfg->obs_layout == PTG_OBS_FEATURE_MAJOR);
     memset(&h->P, 0, sizeof h->P);
     DevParams& P = h->P;
     int rc = 0;
@@ -865,10 +1027,26 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     double2* d_sc;
     if ((rc = dev_upload(h, &d_sc, sc.data(), sc.size()))) return fail(rc);
     P.sincos = d_sc;
+    {
+        std::vector<float2> sc32(sc.size());
+        for (size_t q = 0; q < sc.size(); q++) sc32[q] = make_float2((float)sc[q].x, (float)sc[q].y);
+        float2* d_sc32;
+        if ((rc = dev_upload(h, &d_sc32, sc32.data(), sc32.size()))) return fail(rc);
+        P.sincos32 = d_sc32;
+    }
+    // fast-path records: reward coefficients per window start (k_build_fast)
+    {
+        const double f = P.sim_step_d / 3600;
+        P.k_chp = cfg->convert_mol_to_Nm3 * cfg->H_u_CH4 * 1000 * (cfg->eta_CHP * cfg->eeg_el_price + (1 - cfg->eta_CHP) * cfg->heat_price) * f;
+        P.k_eua = cfg->Molar_mass_CO2 / 1000 / 1000 * 3600 * 100 * f;
+        RecFast* d_recf;
+        if ((rc = dev_alloc(h, &d_recf, h->rec_total))) return fail(rc);
+        hipLaunchKernelGGL(k_build_fast, dim3(grid_for((long long)h->rec_total, 256)), dim3(256), 0, 0, P, P.rec, d_recf, (int)h->rec_total);
+        if ((rc = launch_check(h, "k_build_fast"))) return fail(rc);
+        P.recf = d_recf;
+    }
 
-    if ((rc = dev_alloc(h, &P.st_i, n_envs)) || (rc = dev_alloc(h, &P.st_j, n_envs)) || (rc = dev_alloc(h, &P.st_k, n_envs)) ||
-        (rc = dev_alloc(h, &P.st_flags, n_envs)) || (rc = dev_alloc(h, &P.st_actd, n_envs)) || (rc = dev_alloc(h, &P.st_nctr, n_envs)) ||
-        (rc = dev_alloc(h, &P.st_nchg, n_envs)) || (rc = dev_alloc(h, &P.st_epp, n_envs)) || (rc = dev_alloc(h, &P.st_cum, n_envs)))
+    if ((rc = dev_alloc(h, &P.st_a, n_envs)) || (rc = dev_alloc(h, &P.st_b, n_envs)) || (rc = dev_alloc(h, &P.st_c, n_envs)))
         return fail(rc);
     P.fin_cap = std::max(2 * n_envs, 1024);
     if ((rc = dev_alloc(h, &P.fin_ret, P.fin_cap)) || (rc = dev_alloc(h, &P.fin_len, P.fin_cap)) ||
@@ -889,13 +1067,14 @@ int ptg_set_market_assignment(ptg_env* h, const uint8_t* set_of_env_host)
 {
     if (!h || !set_of_env_host) return set_err(h, PTG_E_INVALID, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
-    std::vector<unsigned> fl(h->n);
-    HIP_TRY(h, hipMemcpy(fl.data(), h->P.st_flags, sizeof(unsigned) * h->n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipDeviceSynchronize());
+    std::vector<StA> a(h->n);
+    HIP_TRY(h, hipMemcpy(a.data(), h->P.st_a, sizeof(StA) * h->n, hipMemcpyDeviceToHost));
     for (int e = 0; e < h->n; e++) {
         if (set_of_env_host[e] >= h->n_sets) return set_err(h, PTG_E_INVALID, "env %d: market set %d out of range", e, set_of_env_host[e]);
-        fl[e] = (fl[e] & ~(3u << 15)) | ((unsigned)set_of_env_host[e] << 15);
+        a[e].flags = (a[e].flags & ~(3u << 15)) | ((unsigned)set_of_env_host[e] << 15);
     }
-    HIP_TRY(h, hipMemcpy(h->P.st_flags, fl.data(), sizeof(unsigned) * h->n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->P.st_a, a.data(), sizeof(StA) * h->n, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -942,7 +1121,9 @@ int ptg_set_noise_tape(ptg_env* h, const double* tape_host, int per_env_len)
     if (rc) return rc;
     if (per_env_len > 0)
         HIP_TRY(h, hipMemcpy(h->d_tape, tape_host, sizeof(double) * (size_t)h->n * per_env_len, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemset(h->P.st_nctr, 0, sizeof(int) * h->n));
+    hipLaunchKernelGGL(k_zero_noise_count, dim3(grid_for(h->n, 256)), dim3(256), 0, 0, h->P);
+    if ((rc = launch_check(h, "k_zero_noise_count"))) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
     return 0;
 }
 
@@ -956,8 +1137,8 @@ int ptg_fill_noise_tape(ptg_env* h, uint64_t seed, int per_env_len, void* stream
     hipLaunchKernelGGL(k_fill_noise, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), h->d_tape, h->n, per_env_len,
                        (unsigned long long)seed, h->noise_epoch++, h->env_offset, h->cfg.noise);
     if ((rc = launch_check(h, "k_fill_noise"))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->P.st_nctr, 0, sizeof(int) * h->n, as_stream(stream)));
-    return 0;
+    hipLaunchKernelGGL(k_zero_noise_count, dim3(grid_for(h->n, 256)), dim3(256), 0, as_stream(stream), h->P);
+    return launch_check(h, "k_zero_noise_count");
 }
 
 int ptg_get_noise_tape(ptg_env* h, double* tape_host)
@@ -980,10 +1161,14 @@ int ptg_reset(ptg_env* h, const uint8_t* mask_host, void* obs_dev, void* stream)
         HIP_TRY(h, hipMalloc((void**)&d_mask, h->n));
         HIP_TRY(h, hipMemcpyAsync(d_mask, mask_host, h->n, hipMemcpyHostToDevice, st));
     }
-    if (h->cfg.out_dtype == PTG_OUT_F64)
-        hipLaunchKernelGGL(k_reset<double>, dim3(grid_for(h->n, 256)), dim3(256), 0, st, h->P, d_mask, (double*)obs_dev);
-    else
-        hipLaunchKernelGGL(k_reset<float>, dim3(grid_for(h->n, 256)), dim3(256), 0, st, h->P, d_mask, (float*)obs_dev);
+    const dim3 grid(grid_for(h->n, 256)), block(256);
+    if (h->cfg.out_dtype == PTG_OUT_F64) {
+        if (h->fm) hipLaunchKernelGGL((k_reset<double, false, true, 0>), grid, block, 0, st, h->P, d_mask, (double*)obs_dev);
+        else hipLaunchKernelGGL((k_reset<double, false, false, 0>), grid, block, 0, st, h->P, d_mask, (double*)obs_dev);
+    } else {
+        if (h->fm) hipLaunchKernelGGL((k_reset<float, true, true, 0>), grid, block, 0, st, h->P, d_mask, (float*)obs_dev);
+        else hipLaunchKernelGGL((k_reset<float, true, false, 0>), grid, block, 0, st, h->P, d_mask, (float*)obs_dev);
+    }
     int rc = launch_check(h, "k_reset");
     if (d_mask) { (void)hipStreamSynchronize(st); (void)hipFree(d_mask); }
     if (rc) return rc;
@@ -1004,17 +1189,21 @@ int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev
     hipStream_t st = as_stream(stream);
     const dim3 grid(grid_for(h->n, 256)), block(256);
     const bool f64 = h->cfg.out_dtype == PTG_OUT_F64;
-    if (info_dev) {
-        if (f64) hipLaunchKernelGGL((k_step<double, true>), grid, block, 0, st, h->P, actions_dev, action_kind, (double*)obs_dev,
-                                    (double*)rew_dev, done_dev, (double*)final_obs_dev, info_dev);
-        else hipLaunchKernelGGL((k_step<float, true>), grid, block, 0, st, h->P, actions_dev, action_kind, (float*)obs_dev,
-                                (float*)rew_dev, done_dev, (float*)final_obs_dev, info_dev);
+#define PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, PAC)                                                                     \
+    hipLaunchKernelGGL((k_step<OUT, FAST, INFO, FM, PAC>), grid, block, 0, st, h->P, actions_dev, action_kind, (OUT*)obs_dev, \
+                       (OUT*)rew_dev, done_dev, (OUT*)final_obs_dev, info_dev)
+#define PTG_LAUNCH_STEP(OUT, FAST, INFO, FM)                                                                          \
+    do { if (h->cfg.price_ahead == 13) PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, 13); else PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, 0); } while (0)
+    if (f64) {
+        if (info_dev) { if (h->fm) PTG_LAUNCH_STEP(double, false, true, true); else PTG_LAUNCH_STEP(double, false, true, false); }
+        else { if (h->fm) PTG_LAUNCH_STEP(double, false, false, true); else PTG_LAUNCH_STEP(double, false, false, false); }
+    } else if (info_dev) {      // info rows need the un-reduced reward terms: float32 outputs of the float64 formula
+        if (h->fm) PTG_LAUNCH_STEP(float, false, true, true); else PTG_LAUNCH_STEP(float, false, true, false);
     } else {
-        if (f64) hipLaunchKernelGGL((k_step<double, false>), grid, block, 0, st, h->P, actions_dev, action_kind, (double*)obs_dev,
-                                    (double*)rew_dev, done_dev, (double*)final_obs_dev, nullptr);
-        else hipLaunchKernelGGL((k_step<float, false>), grid, block, 0, st, h->P, actions_dev, action_kind, (float*)obs_dev,
-                                (float*)rew_dev, done_dev, (float*)final_obs_dev, nullptr);
+        if (h->fm) PTG_LAUNCH_STEP(float, true, false, true); else PTG_LAUNCH_STEP(float, true, false, false);
     }
+#undef PTG_LAUNCH_STEP
+#undef PTG_LAUNCH_STEP_
     return launch_check(h, "k_step");
 }
 
@@ -1030,12 +1219,15 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = as_stream(stream);
     const dim3 grid(grid_for(h->n, 256)), block(256);
-    if (h->cfg.out_dtype == PTG_OUT_F64)
-        hipLaunchKernelGGL(k_rollout<double>, grid, block, 0, st, h->P, actions_dev, action_kind, n_steps, (double*)obs_dev,
-                           (double*)rew_dev, done_dev);
-    else
-        hipLaunchKernelGGL(k_rollout<float>, grid, block, 0, st, h->P, actions_dev, action_kind, n_steps, (float*)obs_dev,
-                           (float*)rew_dev, done_dev);
+#define PTG_LAUNCH_ROLL_(OUT, FAST, FM, PAC)                                                                     \
+    hipLaunchKernelGGL((k_rollout<OUT, FAST, FM, PAC>), grid, block, 0, st, h->P, actions_dev, action_kind, n_steps, \
+                       (OUT*)obs_dev, (OUT*)rew_dev, done_dev)
+#define PTG_LAUNCH_ROLL(OUT, FAST, FM)                                                                           \
+    do { if (h->cfg.price_ahead == 13) PTG_LAUNCH_ROLL_(OUT, FAST, FM, 13); else PTG_LAUNCH_ROLL_(OUT, FAST, FM, 0); } while (0)
+    if (h->cfg.out_dtype == PTG_OUT_F64) { if (h->fm) PTG_LAUNCH_ROLL(double, false, true); else PTG_LAUNCH_ROLL(double, false, false); }
+    else { if (h->fm) PTG_LAUNCH_ROLL(float, true, true); else PTG_LAUNCH_ROLL(float, true, false); }
+#undef PTG_LAUNCH_ROLL
+#undef PTG_LAUNCH_ROLL_
     return launch_check(h, "k_rollout");
 }
 
@@ -1053,31 +1245,24 @@ int ptg_get_state(ptg_env* h, int field, void* out_host)
     HIP_TRY(h, hipDeviceSynchronize());
     const int n = h->n;
     const DevParams& P = h->P;
-    auto copy_i = [&](const int* src) -> int {
-        HIP_TRY(h, hipMemcpy(out_host, src, sizeof(int) * n, hipMemcpyDeviceToHost));
-        return 0;
-    };
-    switch (field) {
-    case PTG_F_I: return copy_i(P.st_i);
-    case PTG_F_J: return copy_i(P.st_j);
-    case PTG_F_K: return copy_i(P.st_k);
-    case PTG_F_ACT_EP_D: return copy_i(P.st_actd);
-    case PTG_F_EP_PTR: return copy_i(P.st_epp);
-    case PTG_F_NOISE_COUNT: return copy_i(P.st_nctr);
-    case PTG_F_N_STATE_CHANGES: return copy_i(P.st_nchg);
-    case PTG_F_CUM_REW:
-        HIP_TRY(h, hipMemcpy(out_host, P.st_cum, sizeof(double) * n, hipMemcpyDeviceToHost));
-        return 0;
-    default: break;
-    }
-    std::vector<unsigned> fl(n);
-    HIP_TRY(h, hipMemcpy(fl.data(), P.st_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    std::vector<StA> a(n); std::vector<StB> b(n); std::vector<StC> c(n);
+    HIP_TRY(h, hipMemcpy(a.data(), P.st_a, sizeof(StA) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(b.data(), P.st_b, sizeof(StB) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(c.data(), P.st_c, sizeof(StC) * n, hipMemcpyDeviceToHost));
     int* oi = (int*)out_host;
     double* od = (double*)out_host;
     for (int e = 0; e < n; e++) {
-        const unsigned f = fl[e];
+        const unsigned f = a[e].flags;
         const int pp = (f >> 6) & 7, fq = (f >> 9) & 7;
         switch (field) {
+        case PTG_F_I: oi[e] = a[e].i; break;
+        case PTG_F_J: oi[e] = a[e].j; break;
+        case PTG_F_K: oi[e] = a[e].k; break;
+        case PTG_F_ACT_EP_D: oi[e] = b[e].act_d; break;
+        case PTG_F_EP_PTR: oi[e] = c[e].epp; break;
+        case PTG_F_NOISE_COUNT: oi[e] = c[e].nctr; break;
+        case PTG_F_N_STATE_CHANGES: oi[e] = b[e].nchg; break;
+        case PTG_F_CUM_REW: od[e] = b[e].cum; break;
         case PTG_F_METH_STATE: oi[e] = f & 7; break;
         case PTG_F_HOT_COLD: oi[e] = (f >> 3) & 1; break;
         case PTG_F_STANDBY_TID: oi[e] = ((f >> 4) & 1) ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN; break;
@@ -1100,31 +1285,26 @@ int ptg_set_state(ptg_env* h, int field, const void* in_host)
     HIP_TRY(h, hipDeviceSynchronize());
     const int n = h->n;
     DevParams& P = h->P;
-    auto copy_i = [&](int* dst) -> int {
-        HIP_TRY(h, hipMemcpy(dst, in_host, sizeof(int) * n, hipMemcpyHostToDevice));
-        return 0;
-    };
-    switch (field) {
-    case PTG_F_I: return copy_i(P.st_i);
-    case PTG_F_J: return copy_i(P.st_j);
-    case PTG_F_K: return copy_i(P.st_k);
-    case PTG_F_ACT_EP_D: return copy_i(P.st_actd);
-    case PTG_F_EP_PTR: return copy_i(P.st_epp);
-    case PTG_F_NOISE_COUNT: return copy_i(P.st_nctr);
-    case PTG_F_N_STATE_CHANGES: return copy_i(P.st_nchg);
-    case PTG_F_CUM_REW:
-        HIP_TRY(h, hipMemcpy(P.st_cum, in_host, sizeof(double) * n, hipMemcpyHostToDevice));
-        return 0;
-    default: break;
-    }
-    std::vector<unsigned> fl(n);
-    HIP_TRY(h, hipMemcpy(fl.data(), P.st_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    std::vector<StA> a(n); std::vector<StB> b(n); std::vector<StC> c(n);
+    HIP_TRY(h, hipMemcpy(a.data(), P.st_a, sizeof(StA) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(b.data(), P.st_b, sizeof(StB) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(c.data(), P.st_c, sizeof(StC) * n, hipMemcpyDeviceToHost));
     const int* ii = (const int*)in_host;
     const double* id = (const double*)in_host;
     auto put = [](unsigned f, int shift, unsigned mask, unsigned v) { return (f & ~(mask << shift)) | ((v & mask) << shift); };
     for (int e = 0; e < n; e++) {
-        unsigned f = fl[e];
+        unsigned f = a[e].flags;
         switch (field) {
+        case PTG_F_I: a[e].i = ii[e]; break;
+        case PTG_F_J: a[e].j = ii[e]; break;
+        case PTG_F_K: a[e].k = ii[e]; break;
+        case PTG_F_ACT_EP_D: b[e].act_d = ii[e]; break;
+        case PTG_F_EP_PTR:
+            if (ii[e] < 0 || (P.E > 0 && ii[e] >= P.E)) return set_err(h, PTG_E_INVALID, "episode pointer out of range");
+            c[e].epp = ii[e]; break;
+        case PTG_F_NOISE_COUNT: c[e].nctr = ii[e]; break;
+        case PTG_F_N_STATE_CHANGES: b[e].nchg = ii[e]; break;
+        case PTG_F_CUM_REW: b[e].cum = id[e]; break;
         case PTG_F_METH_STATE: if (ii[e] < 0 || ii[e] > 4) return set_err(h, PTG_E_INVALID, "bad meth_state"); f = put(f, 0, 7, ii[e]); break;
         case PTG_F_HOT_COLD: f = put(f, 3, 1, ii[e] != 0); break;
         case PTG_F_STANDBY_TID: f = put(f, 4, 1, ii[e] == PTG_T_STANDBY_UP); break;
@@ -1148,9 +1328,11 @@ int ptg_set_state(ptg_env* h, int field, const void* in_host)
         }
         default: return set_err(h, PTG_E_INVALID, "unknown state field %d", field);
         }
-        fl[e] = f;
+        a[e].flags = f;
     }
-    HIP_TRY(h, hipMemcpy(P.st_flags, fl.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(P.st_a, a.data(), sizeof(StA) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(P.st_b, b.data(), sizeof(StB) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(P.st_c, c.data(), sizeof(StC) * n, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -1,0 +1,62 @@
+"""Sharding of the env batch over the GPUs of one node.
+
+Env instances are independent: GPU g of G owns the contiguous global env range [g*n, (g+1)*n) with its own
+copy of the (~8 MB) tables and price series, and NO per-step communication.  The reference's only cross-env
+coupling, the module-global `ep_index` (env/ptg_gym_env.py:9,487-493), has a closed form when the envs of a
+vector step terminate together: env with GLOBAL index e takes eps_ind[N_total + e + m*N_total] at its m-th reset
+(`episode_plan`).  The one collective is an all-gather of the finished-episode (return, length) lists for the
+episodic-return statistic (SB3's rollout/ep_rew_mean) -- RCCL over xGMI on GPUs (backend "nccl"), gloo in CPU tests.
+"""
+import numpy as np
+
+
+def shard_range(n_total, world_size, rank):
+    """Contiguous global env range of `rank`; n_total must divide evenly (weak scaling uses n_total = n * world_size)."""
+    if n_total % world_size != 0:
+        raise ValueError(f"n_total={n_total} is not divisible by world_size={world_size}")
+    n = n_total // world_size
+    return rank * n, (rank + 1) * n
+
+
+def episode_plan(n_total, world_size, rank):
+    """(first_ptr, stride) for ptg_set_episode_plan on this rank's shard."""
+    lo, _ = shard_range(n_total, world_size, rank)
+    return n_total + lo, n_total
+
+
+def mixed_scenario_assignment(n_total, world_size, rank, n_sets):
+    """Per-env market set for a mixed-scenario batch: global env e gets set e % n_sets."""
+    lo, hi = shard_range(n_total, world_size, rank)
+    return (np.arange(lo, hi) % n_sets).astype(np.uint8)
+
+
+def all_gather_finished(returns, lengths, device=None, group=None):
+    """All-gather variable-length finished-episode lists over the process group.
+
+    Returns (returns_all, lengths_all) ordered by rank.  Two collectives: the counts, then the padded payload
+    (float64 return + length packed as [max_count, 2]).  With no initialised process group this is the identity."""
+    import torch
+    import torch.distributed as dist
+    returns = np.asarray(returns, dtype=np.float64)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return returns, lengths
+    world = dist.get_world_size(group)
+    dev = torch.device("cpu") if device is None else device
+    cnt = torch.tensor([len(returns)], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    m = max(max(counts), 1)
+    payload = torch.zeros((m, 2), dtype=torch.float64, device=dev)
+    if len(returns):
+        payload[:len(returns), 0] = torch.from_numpy(returns).to(dev)
+        payload[:len(returns), 1] = torch.from_numpy(lengths.astype(np.float64)).to(dev)
+    bufs = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(bufs, payload, group=group)
+    r_all, l_all = [], []
+    for c, b in zip(counts, bufs):
+        b = b.cpu().numpy()
+        r_all.append(b[:c, 0])
+        l_all.append(b[:c, 1].astype(np.int64))
+    return np.concatenate(r_all), np.concatenate(l_all)

@@ -34,7 +34,7 @@ class PtgError(RuntimeError):
 
 
 class HipEngine:
-    def __init__(self, consts, tables, markets, n_envs, device=0, out_dtype="float32"):
+    def __init__(self, consts, tables, markets, n_envs, device=0, out_dtype="float32", obs_layout="row"):
         import torch
         self._torch = torch
         self._L = _lib.lib()                      # raises if the extension is missing
@@ -47,7 +47,8 @@ class HipEngine:
         c = dict(consts)
         c.setdefault("t_cat_initial", 16.0)
         c["out_dtype"] = _lib.OUT_F64 if out_dtype == "float64" else _lib.OUT_F32
-        c["reserved"] = 0
+        c["obs_layout"] = {"row": _lib.OBS_ROW_MAJOR, "feature": _lib.OBS_FEATURE_MAJOR}[obs_layout]
+        self.feature_major = obs_layout == "feature"
         for k in _lib.CONFIG_KEYS:
             setattr(cfg, k, c[k])
         self.consts = c
@@ -83,8 +84,9 @@ class HipEngine:
         self.action_type = int(c["action_type"])
         self.eval_mode = bool(c["train_or_eval"])
         with torch.cuda.device(self.device):
-            self.obs = torch.zeros((self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
-            self.final_obs = torch.zeros((self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
+            shape = (self.obs_dim, self.n) if self.feature_major else (self.n, self.obs_dim)
+            self.obs = torch.zeros(shape, dtype=self.out_dtype, device=self.device)
+            self.final_obs = torch.zeros(shape, dtype=self.out_dtype, device=self.device)
             self.rew = torch.zeros(self.n, dtype=self.out_dtype, device=self.device)
             self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
             self.info = torch.zeros((self.n, _lib.N_INFO), dtype=torch.float64, device=self.device) if self.eval_mode else None
@@ -104,6 +106,10 @@ class HipEngine:
     def _chk(self, rc):
         if rc != 0:
             raise PtgError(rc, self._L.ptg_last_error(self._h).decode())
+
+    def rows(self, obs):
+        """[N, F] (or [T, N, F]) view of an observation buffer in either layout (a transpose view for feature-major)."""
+        return obs.transpose(-1, -2) if self.feature_major else obs
 
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -188,14 +194,15 @@ class HipEngine:
         return obs, rew, done
 
     def rollout(self, actions, obs=None, rew=None, done=None):
-        """T fused steps in one launch: actions [T, N] -> obs [T, N, F], rew [T, N], done [T, N]."""
+        """T fused steps in one launch: actions [T, N] -> obs [T, N, F] ([T, F, N] feature-major), rew [T, N], done [T, N]."""
         torch = self._torch
         a = self.as_device_actions(actions)
         assert a.dim() == 2 and a.shape[1] == self.n
         T = a.shape[0]
         with torch.cuda.device(self.device):
             if obs is None:
-                obs = torch.empty((T, self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
+                shape = (T, self.obs_dim, self.n) if self.feature_major else (T, self.n, self.obs_dim)
+                obs = torch.empty(shape, dtype=self.out_dtype, device=self.device)
             if rew is None:
                 rew = torch.empty((T, self.n), dtype=self.out_dtype, device=self.device)
             if done is None:

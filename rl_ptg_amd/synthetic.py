@@ -25,3 +25,19 @@ def synthetic_market(days=38, seed=SYNTH_SEED):
     """(el, gas [ct/kWh], eua [Euro/t]) as the reference's import_market_data would return them."""
     el, gas, eua = synthetic_market_csv_units(days, seed)
     return el.astype(float) / 10, gas.astype(float) / 10, eua.astype(float)
+
+
+def sticky_actions_device(n_steps, n_envs, seed, device, p_switch=1.0 / 12.0):
+    """Synthetic action tape [n_steps, n_envs] int32 on `device`: per-env i.i.d. uniform{0..4} actions held for
+    ~Geom(p_switch) steps; p_switch = 1 gives the adversarial uniform-random-every-step tape."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    out = torch.empty((n_steps, n_envs), dtype=torch.int32, device=device)
+    cur = torch.randint(0, 5, (n_envs,), generator=g, device=device, dtype=torch.int32)
+    for t in range(n_steps):
+        sw = torch.rand((n_envs,), generator=g, device=device) < p_switch
+        new = torch.randint(0, 5, (n_envs,), generator=g, device=device, dtype=torch.int32)
+        cur = torch.where(sw, new, cur)
+        out[t] = cur
+    return out

@@ -62,12 +62,12 @@ def market_for_engine(consts, market, prep_meta=None):
     return m
 
 
-def make_engine(case, out_dtype="float64", n_envs=None):
+def make_engine(case, out_dtype="float64", n_envs=None, obs_layout="row"):
     """HIP engine on cuda:0 configured exactly like the reference run that produced the fixture."""
     from rl_ptg_amd.engine import HipEngine
     tr, consts, tables, market = load_traj(case)
     n = tr["meta"]["n_envs"] if n_envs is None else n_envs
-    eng = HipEngine(consts, tables, market_for_engine(consts, market), n, device=0, out_dtype=out_dtype)
+    eng = HipEngine(consts, tables, market_for_engine(consts, market), n, device=0, out_dtype=out_dtype, obs_layout=obs_layout)
     eng.set_noise_tape(tr["noise"])
     if market["eps_ind"] is not None:
         # DummyVecEnv order: n constructions consume eps_ind[0:n], the first vector reset takes eps_ind[n + e]

@@ -22,13 +22,13 @@ def _ints(eng):
     return np.stack(cols + [actd * 24, actd], axis=1)
 
 
-@pytest.mark.parametrize("out_dtype", ["float64", "float32"])
+@pytest.mark.parametrize("out_dtype,layout", [("float64", "row"), ("float32", "row"), ("float32", "feature"), ("float64", "feature")])
 @pytest.mark.parametrize("case", H.TRAJ_CASES)
-def test_trajectory_vs_reference_golden(case, out_dtype):
-    tr, eng = H.make_engine(case, out_dtype)
+def test_trajectory_vs_reference_golden(case, out_dtype, layout):
+    tr, eng = H.make_engine(case, out_dtype, obs_layout=layout)
     rtol, atol = (RTOL64, ATOL64) if out_dtype == "float64" else (RTOL32, ATOL32)
     K, n = tr["actions"].shape
-    obs0 = eng.reset().cpu().numpy()
+    obs0 = eng.rows(eng.reset()).cpu().numpy()
     np.testing.assert_allclose(obs0, tr["reset_obs"], rtol=rtol, atol=atol)
     assert np.array_equal(_ints(eng), tr["reset_int"])
     post_at = [tuple(x) for x in tr["post_reset_at"].tolist()]
@@ -39,11 +39,11 @@ def test_trajectory_vs_reference_golden(case, out_dtype):
     for t in range(K):
         obs, rew, done = eng.step(tr["actions"][t])
         eng.sync()
-        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        obs, rew, done = eng.rows(obs).cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
         assert np.array_equal(done, tr["done"][t]), f"done differs at step {t}"
         np.testing.assert_allclose(rew, tr["f64s"][t, :, 0], rtol=rtol, atol=atol, err_msg=f"reward, step {t}")
         ret_acc += tr["f64s"][t, :, 0]
-        final = eng.final_obs.cpu().numpy()
+        final = eng.rows(eng.final_obs).cpu().numpy()
         any_done = bool(done.any())
         if any_done or t % check_every == 0 or t == K - 1:
             ints = _ints(eng)
@@ -124,11 +124,11 @@ def test_device_built_window_records_match_numpy_average(case):
     eng.close()
 
 
-@pytest.mark.parametrize("out_dtype", ["float64", "float32"])
-def test_rollout_equals_steps(out_dtype):
+@pytest.mark.parametrize("out_dtype,layout", [("float64", "row"), ("float32", "row"), ("float32", "feature")])
+def test_rollout_equals_steps(out_dtype, layout):
     case = "synth_bs2_op2_term_penalty"
-    tr, e1 = H.make_engine(case, out_dtype)
-    _, e2 = H.make_engine(case, out_dtype)
+    tr, e1 = H.make_engine(case, out_dtype, obs_layout=layout)
+    _, e2 = H.make_engine(case, out_dtype, obs_layout=layout)
     K = 400
     e1.reset(); e2.reset()
     obs_r, rew_r, done_r = e2.rollout(tr["actions"][:K])
