@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--obs-layout", choices=["row", "feature"], default="feature",
                     help="observation matrix layout: feature-major [F][N] (coalesced SoA stores) or row-major [N][F]")
     ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
+    ap.add_argument("--noise", choices=["rng", "tape"], default="rng", help="in-kernel counter RNG or a device-filled tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,8 +113,11 @@ def main():
     eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
     first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
     eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
-    tape_len = min(max(K + W + 8, 64), 1024)
-    eng.fill_noise_tape(seed=20250614 + rank, per_env_len=tape_len)
+    eng.set_global_env_offset(first_ptr - n_total)
+    if args.noise == "rng":
+        eng.set_noise_rng(seed=20250614)                  # counter-based draws inside the kernels
+    else:
+        eng.fill_noise_tape(seed=20250614, per_env_len=min(max(K + W + 8, 64), 1024))
     actions = sticky_actions_device(K + W, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
     eng.reset()
 
@@ -176,7 +180,7 @@ def main():
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} envs/GPU, BS{args.scenario}/{args.operation}, synthetic 38-day trace (32-day episodes), "
-                                   f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), device noise tape",
+                                   f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), noise: {args.noise}",
                        "path": "ptg_step (one launch per vector step)" if args.path == "step" else "ptg_rollout (K steps fused in one launch)",
                        "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype, "obs_dim": eng.obs_dim, "obs_layout": args.obs_layout,
                        "parallelism": f"env-sharded x{world}, no per-step collective"},

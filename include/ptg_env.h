@@ -130,8 +130,15 @@ int ptg_set_episode_plan(ptg_env* env, const double* eps_ind_host, int n, int64_
 /* Normal draws consumed at state changes (:584-585,598-599,620-621): the c-th draw of env e is tape[e*len + c mod len].
  * Host tape (e.g. numpy Generator.normal(0, noise) per env for bit parity with the reference) ... */
 int ptg_set_noise_tape(ptg_env* env, const double* tape_host, int per_env_len);
-/* ... or filled on the device: Philox4x32-10 keyed by (seed, epoch) + Box-Muller, sigma = cfg.noise. Resets the counters. */
+/* ... or the device's counter-based generator: the c-th draw of the env with GLOBAL index g is
+ *   noise(seed, g, c) = cfg.noise * BoxMuller(Philox4x32-10(key = seed, counter = (c, g)))   (float32 Box-Muller, native log/cos).
+ * ptg_set_noise_rng draws it inside the step kernels (no tape, unbounded); ptg_fill_noise_tape writes the first per_env_len
+ * draws of the same streams to the tape (so both modes give identical trajectories while the tape does not wrap).
+ * Both reset the per-env draw counters.  Statistically equivalent to, not bit-equal with, NumPy's Generator.normal. */
+int ptg_set_noise_rng(ptg_env* env, uint64_t seed);
 int ptg_fill_noise_tape(ptg_env* env, uint64_t seed, int per_env_len, void* stream);
+/* global index of this handle's env 0 (multi-GPU shards): keys the RNG streams; default 0 */
+int ptg_set_global_env_offset(ptg_env* env, int64_t offset);
 int ptg_get_noise_tape(ptg_env* env, double* tape_host);          /* [n_envs][per_env_len] */
 
 /* ---- the hot path --------------------------------------------------------------------------------------- */

@@ -57,8 +57,9 @@ static_assert(sizeof(RecFast) == 64, "RecFast must be 64 bytes");
 // Per-env state, three arrays of naturally aligned structs (16-B / 16-B / 8-B lanes -> dwordx4 / dwordx2 accesses)
 struct alignas(16) StA { int i, j, k; unsigned flags; };   // flags: [0:3) meth_state [3] hot_cold [4] standby=up [5] startup=hot
                                                             // [6:9) part_op [9:12) full_op [12:15) current_action [15:17) market set [17:32) T key
-struct alignas(16) StB { double cum; int act_d; int nchg; };   // cum_rew (:330), act_ep_d (:61,492), state changes this episode
-struct alignas(8) StC { int nctr; int epp; };                  // noise draws consumed, pointer into eps_ind (touched on transitions / resets only)
+struct alignas(16) StB { double cum; int act_d; int nctr; };   // cum_rew (:330), act_ep_d (:61,492), noise draws consumed so far
+struct alignas(8) StC { int nchg; int epp; };                  // state changes this episode (tracked when the penalty is on), pointer into
+                                                               // eps_ind -- touched on penalised state changes / resets only
 
 struct Regs {
     StA a; StB b; StC c;
@@ -68,6 +69,11 @@ struct Regs {
 struct DevParams {
     int N, S, sim_step, eps_sim_steps, PA, F, mod, eps_len_d;
     int E, ep_stride;                      // eps_ind length (0 = eval env), pointer stride (mod E)
+    int noise_inline, track_changes;       // draw noise from the counter RNG in the kernel; maintain StC.nchg (penalty != 0)
+    unsigned long long noise_seed;
+    long long env_offset;                  // global index of env 0 of this shard (keys the RNG streams)
+    double noise_sigma;
+    int dbg;                               // PTG_DEBUG_FLAGS (timing experiments only; 0 in production)
     int key_cold_max, key_hot_min, key_standby_max, key_init, i_reset, nT, tape_len;
     int n_hours, n_days, hstride, dstride;
     int t1_start_p_f, t2_start_f_p, t_p_f, t_f_p, t1_p_f_p, t2_p_f_p, t3_p_f_p, t34_p_f_p, t4_p_f_p, t45_p_f_p,
@@ -177,33 +183,32 @@ __global__ void k_build_argmin(const double* __restrict__ tab, int n, const doub
 }
 
 // ------------------------------------------------------------------------------------------------ noise tape RNG
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned out[4])
+// c-th normal(0, sigma) draw of global env eg: a counter-based generator built from three rounds of the 32-bit
+// integer finaliser "lowbias32" (x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16) keyed by
+// (seed, eg, c), then Box-Muller in float32 with the native log / cos (~30 VALU instead of ~150 for Philox4x32-10 +
+// float64 Box-Muller; the draw only jitters a table row index by ~10 rows).  The same function fills tapes
+// (k_fill_noise) and draws in-kernel, so both modes agree bit for bit.
+__device__ __forceinline__ unsigned lowbias32(unsigned x)
 {
-    for (int r = 0; r < 10; r++) {
-        unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ double noise_draw(unsigned long long seed, long long eg, unsigned c, double sigma)
+{
+    const unsigned k0 = lowbias32((unsigned)eg ^ (unsigned)seed);
+    const unsigned k1 = lowbias32(k0 + c * 0x9E3779B9u + (unsigned)(seed >> 32) + (unsigned)(eg >> 32) * 0x85EBCA6Bu);
+    const unsigned k2 = lowbias32(k1 ^ 0xC2B2AE35u);
+    const float u1 = ((float)(k1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(k2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    return sigma * (double)(r * __cosf(6.28318530717958647692f * u2));
 }
 
-__global__ void k_fill_noise(double* __restrict__ tape, int N, int L, unsigned long long seed, unsigned epoch,
-                             long long env_offset, double sigma)
+__global__ void k_fill_noise(double* __restrict__ tape, int N, int L, unsigned long long seed, long long env_offset, double sigma)
 {
     long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)N * L) return;
-    int c = (int)(g % L);
-    long long e = g / L + env_offset;
-    unsigned o[4];
-    philox4x32_10((unsigned)c, epoch, (unsigned)e, (unsigned)(e >> 32), (unsigned)seed, (unsigned)(seed >> 32), o);
-    unsigned long long a = ((unsigned long long)o[0] << 21) ^ (o[1] >> 11);   // 53 bits
-    unsigned long long b = ((unsigned long long)o[2] << 21) ^ (o[3] >> 11);
-    double u1 = ((double)(a & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
-    double u2 = ((double)(b & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
-    tape[g] = sigma * (sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+    tape[g] = noise_draw(seed, g / L + env_offset, (unsigned)(g % L), sigma);
 }
 
 // ------------------------------------------------------------------------------------------------ the env step
@@ -242,8 +247,21 @@ __device__ __forceinline__ int decode_action(const void* actions, int kind, size
     return (int)(a < 0 ? a + 5 : a);      // python list indexing: actions[-1] is full_load
 }
 
+// Where the small lookup tables live: global memory (L2-resident) or LDS copies staged by the workgroup.
+struct LutGlobal {            // _get_index lookup [6][nT] int32
+    const int* p; int nT;
+    __device__ __forceinline__ int get(int dest, int tkey) const { return p[dest * nT + tkey]; }
+};
+struct LutLds {               // the same as uint16 in LDS (every table has < 65536 rows)
+    const unsigned short* p; int nT;
+    __device__ __forceinline__ int get(int dest, int tkey) const { return (int)p[dest * nT + tkey]; }
+};
+
 // Integer state machine of step() (:339-440) and _perform_sim_step (:525-557).  Returns the record index.
-__device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, int e, bool& changed)
+// The two memory lookups a state change needs (_get_index entry, noise draw) are issued BEFORE the branchy part so
+// that they overlap; the branches then hold integer arithmetic only.
+template <class LUT>
+__device__ __forceinline__ int step_ints(const DevParams& P, const int2* tabmeta, const LUT& lut, Regs& R, int act, int e, bool& changed)
 {
     unsigned f = R.a.flags;
     int s = f & 7, hot = (f >> 3) & 1, sb = (f >> 4) & 1, su = (f >> 5) & 1, pp = (f >> 6) & 7, fq = (f >> 9) & 7;
@@ -255,6 +273,7 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
     const int prev = s;
     const int S = P.S;
     int i = R.a.i, j = R.a.j, table;
+    const int time_op = i + j * S;
     // :368-440 dispatch
     int kind;   // 0 continue, 1 _standby, 2 _cooldown, 3 _startup, 4 _partial, 5 _full
     if (act == 0) kind = (s == 0) ? 0 : 1;
@@ -262,6 +281,17 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
     else if (act == 2) kind = (s <= 1) ? 3 : 0;
     else if (act == 3) kind = (s == 4) ? 4 : 0;
     else kind = (s == 3) ? 5 : 0;
+    // lookups for the transition, hoisted: destination table of _get_index and the noise draw
+    const bool sb_new = (tkey <= P.key_standby_max);
+    const bool noisy = (kind >= 1 && kind <= 3);
+    const int dest = (kind == 1) ? (sb_new ? 1 : 2) : (kind == 3) ? (hot ? 4 : 3) : (kind == 4) ? 5 : 0;
+    const int idx = lut.get(dest, tkey);
+    double z = 0.0;
+    if (noisy) {
+        if (P.tape_len > 0) z = P.tape[(size_t)e * P.tape_len + ((unsigned)R.b.nctr % (unsigned)P.tape_len)];
+        else if (P.noise_inline) z = noise_draw(P.noise_seed, P.env_offset + e, (unsigned)R.b.nctr, P.noise_sigma);
+        R.b.nctr += 1;
+    }
 
     if (kind == 0) {                                       // _cont (:559-570)
         table = (s == 0) ? (sb ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN)
@@ -269,25 +299,18 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
               : (s == 2) ? (su ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD)
               : (s == 3) ? part_tid(pp) : full_tid(fq);
         j += 1;
-    } else if (kind <= 3) {                                // _standby / _cooldown / _startup (:572-625)
-        int dest;
-        if (kind == 1) { s = 0; sb = (tkey <= P.key_standby_max); table = sb ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN; dest = sb ? 1 : 2; }
-        else if (kind == 2) { s = 1; table = PTG_T_COOLDOWN; dest = 0; }
-        else { s = 2; pp = 0; fq = 0; su = hot; table = su ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD; dest = su ? 4 : 3; }
-        const int idx = P.argidx[dest * P.nT + tkey];
-        need_c(P, e, R);
-        double z = 0.0;
-        if (P.tape_len > 0) z = P.tape[(size_t)e * P.tape_len + (R.c.nctr % P.tape_len)];
-        R.c.nctr += 1; R.c_dirty = true;
+    } else if (noisy) {                                    // _standby / _cooldown / _startup (:572-625)
+        if (kind == 1) { s = 0; sb = sb_new; table = sb ? PTG_T_STANDBY_UP : PTG_T_STANDBY_DOWN; }
+        else if (kind == 2) { s = 1; table = PTG_T_COOLDOWN; }
+        else { s = 2; pp = 0; fq = 0; su = hot; table = su ? PTG_T_STARTUP_HOT : PTG_T_STARTUP_COLD; }
         double x = (double)idx + z;                        // int(max(idx + normal, 0)) (:584-585)
         if (0 > x) x = 0;
         i = (int)x;
         j = 1;
     } else if (kind == 4) {                                // _partial (:627-691)
         s = 3;
-        const int time_op = i + j * S;
         if (fq == 0) {
-            if (time_op < P.t2_start_f_p) { pp = 0; i = P.argidx[5 * P.nT + tkey]; j = 1; }
+            if (time_op < P.t2_start_f_p) { pp = 0; i = idx; j = 1; }
             else { pp = 5; i = 0; j = 1; }
         } else if (fq == 1) {
             if (time_op < P.t1_p_f_p) { pp = 5; i = P.i_full; j = P.j_full; }
@@ -301,7 +324,6 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
         table = part_tid(pp);
     } else {                                               // _full (:693-757)
         s = 4;
-        const int time_op = i + j * S;
         if (pp == 0) {
             fq = (time_op < P.t1_start_p_f) ? 0 : 1; i = 0; j = 1;
         } else if (pp == 5) {
@@ -316,7 +338,7 @@ __device__ __forceinline__ int step_ints(const DevParams& P, Regs& R, int act, i
         table = full_tid(fq);
     }
     // _perform_sim_step (:525-557) against the virtual table [rows | splice-or-last-row padding]
-    const int2 tm = P.tabmeta[table];
+    const int2 tm = tabmeta[table];
     const int n = tm.x;
     const int start = i + (j - 1) * S;
     int r;
@@ -420,7 +442,8 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, int e, co
     }
     const unsigned keep = R.a.flags & ((7u << 12) | (3u << 15));     // current_action survives reset(); market set is fixed
     R.a.flags = 1u | keep | ((unsigned)P.key_init << 17);            // cooldown, cold, standby_down, startup_cold, op1, op2
-    R.a.i = P.i_reset; R.a.j = 0; R.a.k = 0; R.b.cum = 0.0; R.b.nchg = 0;
+    R.a.i = P.i_reset; R.a.j = 0; R.a.k = 0; R.b.cum = 0.0;
+    if (P.track_changes) { need_c(P, e, R); R.c.nchg = 0; R.c_dirty = true; }
     if (row) {
         const unsigned mset = (R.a.flags >> 15) & 3;
         PriceFeatures<OUT, FAST, FM, PAC> pf;
@@ -440,9 +463,9 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, int e, co
 }
 
 // One env step.  Returns terminated.
-template <typename OUT, bool FAST, bool INFO, bool FM, int PAC>
-__device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int act, const ObsRow<OUT, FM>& row, OUT* rew_out,
-                                         double* info_row)
+template <typename OUT, bool FAST, bool INFO, bool FM, int PAC, class LUT>
+__device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta, const LUT& lut, Regs& R, int e, int act,
+                                         const ObsRow<OUT, FM>& row, OUT* rew_out, double* info_row)
 {
     // :442-450 clock and price columns at time (k+1)*dt -- independent of the state machine, so these loads go first
     const unsigned mset = (R.a.flags >> 15) & 3;
@@ -462,7 +485,8 @@ __device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int
     PriceFeatures<OUT, FAST, FM, PAC> pf;
     if (row) pf.load(P, mset, H, D);
     bool changed;
-    const int ridx = step_ints(P, R, act, e, changed);
+    int ridx = step_ints(P, tabmeta, lut, R, act, e, changed);
+    if (P.dbg & 2) ridx = ridx & 1023;
     const int s = R.a.flags & 7;
     double rew;
     if (FAST) {
@@ -470,7 +494,7 @@ __device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int
         R.a.flags = (R.a.flags & 0x1FFFFu) | ((unsigned)rec.tkey << 17);   // Meth_T_cat = op[-1, 1] (:452)
         rew = rec.base + rec.ch4 * (setc.x * P.k_chp + P.k_eua * eua) + rec.c_gas * gas - rec.c_el * el;
         R.b.cum += rew;
-        if (changed) { rew -= setc.y; R.b.nchg += 1; }
+        if (changed) { rew -= setc.y; if (P.track_changes) { need_c(P, e, R); R.c.nchg += 1; R.c_dirty = true; } }
         *rew_out = (OUT)rew;
         if (row) {
             const float2 sc = P.sincos32[kk];
@@ -516,7 +540,7 @@ __device__ __forceinline__ bool env_step(const DevParams& P, Regs& R, int e, int
         const double cost_water = (H2O + water_elz) / P.rho * P.water_price;
         rew = (ch4_rev + chp_rev + steam_rev + eua_rev + o2_rev - cost_el - cost_water) * P.sim_step_d / 3600;
         R.b.cum += rew;
-        if (changed) { rew -= setc.y; R.b.nchg += 1; }
+        if (changed) { rew -= setc.y; if (P.track_changes) { need_c(P, e, R); R.c.nchg += 1; R.c_dirty = true; } }
         *rew_out = (OUT)rew;
         // :206-217 + :219-249 observation row
         if (row) {
@@ -568,14 +592,18 @@ __global__ void __launch_bounds__(256)
 k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT* __restrict__ obs, OUT* __restrict__ rew,
        uint8_t* __restrict__ done, OUT* __restrict__ final_obs, double* __restrict__ info)
 {
+    __shared__ int2 s_tm[NT];
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e < P.N;
     bool term = false;
     Regs R;
     double ret = 0.0;
     int len = 0;
+    if (live) load_regs(P, e, R);                        // state loads in flight while the table meta is staged
+    if (threadIdx.x < NT) s_tm[threadIdx.x] = P.tabmeta[threadIdx.x];
+    __syncthreads();
+    const LutGlobal lut{P.argidx, P.nT};
     if (live) {
-        load_regs(P, e, R);
         const int act = decode_action(actions, action_kind, e, (R.a.flags >> 12) & 7);
         if (act < 0) {
             atomicOr(P.err, 1);
@@ -585,7 +613,7 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
             const ObsRow<OUT, FM> row(obs, P, e);
             double* irow = (INFO && info) ? info + (size_t)e * PTG_N_INFO : nullptr;
             OUT r;
-            term = env_step<OUT, FAST, INFO, FM, PAC>(P, R, e, act, row, &r, irow);
+            term = env_step<OUT, FAST, INFO, FM, PAC>(P, s_tm, lut, R, e, act, row, &r, irow);
             rew[e] = r;
             done[e] = term ? 1 : 0;
             if (term) {
@@ -593,7 +621,8 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
                     const ObsRow<OUT, FM> frow(final_obs, P, e);
                     for (int q = 0; q < P.F; q++) frow.put(q, row.get(q));
                 }
-                ret = R.b.cum - (double)R.b.nchg * P.setc[(R.a.flags >> 15) & 3].y;
+                ret = R.b.cum;
+                if (P.track_changes) { need_c(P, e, R); ret -= (double)R.c.nchg * P.setc[(R.a.flags >> 15) & 3].y; }
                 len = R.a.k;
                 reset_env<OUT, FAST, FM, PAC>(P, R, e, row);
             }
@@ -603,35 +632,60 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
     push_finished(P, live && term, e, ret, len);
 }
 
-template <typename OUT, bool FAST, bool FM, int PAC>
-__global__ void __launch_bounds__(256)
+// T fused steps: state in registers, table meta + (when it fits, LDSLUT) the uint16 _get_index lookup in LDS, next action
+// prefetched.  One lane per env; block size is chosen by the host so that >= 256 workgroups exist (one per CU).
+template <typename OUT, bool FAST, bool FM, int PAC, bool LDSLUT>
+__global__ void __launch_bounds__(1024)
 k_rollout(const DevParams P, const void* __restrict__ actions, int action_kind, int T, OUT* __restrict__ obs,
-          OUT* __restrict__ rew, uint8_t* __restrict__ done)
+          OUT* __restrict__ rew, uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int2* s_tm = (int2*)s_dyn;                                     // [NT]  (aligned(16): Guideline 17)
+    unsigned short* s_lut = (unsigned short*)(s_dyn + 16 * ((NT * sizeof(int2) + 15) / 16));
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e < P.N;
     Regs R;
     if (live) load_regs(P, e, R);
+    if (threadIdx.x < NT) s_tm[threadIdx.x] = P.tabmeta[threadIdx.x];
+    if (LDSLUT) {
+        const int words = (N_DEST * P.nT + 1) / 2;                 // copy as 32-bit words
+        const unsigned* src = (const unsigned*)lut16;
+        unsigned* dst = (unsigned*)s_lut;
+        for (int q = threadIdx.x; q < words; q += blockDim.x) dst[q] = src[q];
+    }
+    __syncthreads();
     bool bad = false;
     const size_t NF = (size_t)P.N * P.F;
+    int act_raw = 0; float act_f = 0.f;
+    auto fetch = [&](int t) {                                       // raw action of step t (decoded when used)
+        const size_t g = (size_t)t * P.N + e;
+        if (action_kind == PTG_ACT_F32) act_f = ((const float*)actions)[g];
+        else if (action_kind == PTG_ACT_I64) { long long v = ((const long long*)actions)[g]; act_raw = (v < -5 || v > 4) ? 99 : (int)v; }
+        else act_raw = ((const int*)actions)[g];
+    };
+    if (live) fetch(0);
     for (int t = 0; t < T; t++) {
         bool term = false;
         double ret = 0.0;
         int len = 0;
         if (live && !bad) {
             const size_t g = (size_t)t * P.N + e;
-            const int act = decode_action(actions, action_kind, g, (R.a.flags >> 12) & 7);
+            const int act = (action_kind == PTG_ACT_F32) ? decode_action(&act_f, PTG_ACT_F32, 0, (R.a.flags >> 12) & 7)
+                                                          : decode_action(&act_raw, PTG_ACT_I32, 0, 0);
+            if (t + 1 < T) fetch(t + 1);
             if (act < 0) {
                 atomicOr(P.err, 1);
                 bad = true;
             } else {
-                const ObsRow<OUT, FM> row(obs + (size_t)t * NF, P, e);
+                const ObsRow<OUT, FM> row((P.dbg & 1) ? nullptr : obs + (size_t)t * NF, P, e);
                 OUT r;
-                term = env_step<OUT, FAST, false, FM, PAC>(P, R, e, act, row, &r, nullptr);
+                if (LDSLUT) term = env_step<OUT, FAST, false, FM, PAC>(P, s_tm, LutLds{s_lut, P.nT}, R, e, act, row, &r, nullptr);
+                else term = env_step<OUT, FAST, false, FM, PAC>(P, s_tm, LutGlobal{P.argidx, P.nT}, R, e, act, row, &r, nullptr);
                 rew[g] = r;
                 done[g] = term ? 1 : 0;
                 if (term) {
-                    ret = R.b.cum - (double)R.b.nchg * P.setc[(R.a.flags >> 15) & 3].y;
+                    ret = R.b.cum;
+                    if (P.track_changes) { need_c(P, e, R); ret -= (double)R.c.nchg * P.setc[(R.a.flags >> 15) & 3].y; }
                     len = R.a.k;
                     reset_env<OUT, FAST, FM, PAC>(P, R, e, row);
                 }
@@ -664,15 +718,15 @@ __global__ void k_init_state(const DevParams P, int first_ptr_mod, int have_plan
     }
     StA a; a.i = 0; a.j = 0; a.k = 0;
     a.flags = 1u | (1u << 12) | ((unsigned)P.key_init << 17);   // cooldown, current_action = 'cooldown' (:143)
-    StB b; b.cum = 0.0; b.act_d = 0; b.nchg = 0;
-    StC c; c.nctr = 0; c.epp = 0;
+    StB b; b.cum = 0.0; b.act_d = 0; b.nctr = 0;
+    StC c; c.nchg = 0; c.epp = 0;
     P.st_a[e] = a; P.st_b[e] = b; P.st_c[e] = c;
 }
 
 __global__ void k_zero_noise_count(const DevParams P)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < P.N) P.st_c[e].nctr = 0;
+    if (e < P.N) P.st_b[e].nctr = 0;
 }
 
 // fast-path records from the window records: reward coefficients (:280-334) and normalised features (:212-217)
@@ -713,6 +767,351 @@ __global__ void k_build_fast(const DevParams P, const Rec* __restrict__ in, RecF
     out[g] = o;
 }
 
+
+// ================================================================================================ hot kernels
+// Dedicated float32 kernels for the common case: 13-hour look-ahead, no info rows, and NO env terminating inside the launch
+// (the host tracks the common step count of a synchronised batch and routes the one step per episode that terminates --
+// and everything unusual -- through the generic kernels above).  Same arithmetic as env_step<float, FAST>, laid out for a
+// machine that runs ONE wave per SIMD at N = 65 536 (1024 waves on 1024 SIMDs), where nothing hides latency but the order
+// of the instruction stream:
+//   * few scalars: HotParams carries only what every step needs; ladder thresholds, table meta data and the _get_index
+//     lookup sit in LDS;
+//   * every address is (uniform base) + (32-bit lane byte offset): SGPR-base global_load / global_store, no 64-bit VALU math;
+//   * the integer state machine is branch-free (select chains in the reference's if / elif priority order); only two
+//     wave-uniform branches remain (some lane changes state; some lane switches partial <-> full load);
+//   * front(): issues ALL loads of a step in one burst (market features merged into dwordx4, prices, record gather);
+//   * k_rollout_hot is software-pipelined: the loads of step t+1 are issued BEFORE the 37 stores of step t, because vmcnt
+//     retires loads and stores in issue order -- a load issued behind the stores waits for their write acknowledgements.
+// Measured and rejected on MI355X: a "broadcast" form that stores the 28 features a synchronised wave shares
+// as 7 dwordx4 (its uniformity tests cost more than the 21 stores it saves), and 32 / 16 envs per wave for more waves per SIMD.
+template <typename T>
+__device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) { return *(const T*)((const char*)base + byte_off); }
+template <typename T>
+__device__ __forceinline__ void st_off(void* base, unsigned byte_off, T v) { *(T*)((char*)base + byte_off) = v; }
+
+enum { LAD_T1_START_P_F = 0, LAD_T2_START_F_P, LAD_T_P_F, LAD_T_F_P, LAD_T1_P_F_P, LAD_T2_P_F_P, LAD_T3_P_F_P, LAD_T34_P_F_P,
+       LAD_T4_P_F_P, LAD_T45_P_F_P, LAD_T5_P_F_P, LAD_T1_F_P_F, LAD_T2_F_P_F, LAD_T23_F_P_F, LAD_T3_F_P_F, LAD_T34_F_P_F,
+       LAD_T4_F_P_F, LAD_T45_F_P_F, LAD_T5_F_P_F, LAD_I_FULL, LAD_J_FULL, LAD_N };
+
+struct HotParams {
+    int N, S, sim_step, eps_sim_steps, F, nT, tape_len, track_changes;
+    int key_cold_max, key_hot_min, key_standby_max, n_hours, n_days, hstride, dstride, dbg;
+    unsigned off_featB, off_gasn, off_euan, off_sc;   // element offsets into pool32 (featA at 0; sin/cos pairs at off_sc)
+    unsigned off_gas, off_eua;                        // element offsets into pool64 (el at 0)
+    unsigned long long noise_seed;
+    long long env_offset;
+    double noise_sigma, k_chp, k_eua;
+    const RecFast* recf;
+    const double* tape;
+    const float* pool32;
+    const double* pool64;
+    const double2* setc;
+    const int* argidx;
+    const int2* tabmeta;
+    const int* ladder;                                // [LAD_N]
+    StA* st_a; StB* st_b; StC* st_c;
+    int* err;
+};
+
+struct HotLds {                  // per-workgroup LDS image
+    int2 tm[NT + 1];
+    int lad[LAD_N + 3];
+};
+
+struct HotRegs {                 // per-env state in registers
+    int i, j, k;
+    unsigned flags;
+    double cum;
+    int act_d, nctr;
+};
+
+struct HotLoads {                // everything front() fetched for one step
+    float fa[13], fb[13];        // Pot_Reward, Part_Full ('raw': Elec_Price; Gas_Price[2], EUA_Price[2] in fb[0..3])
+    float2 sc;                   // Temp_hour_enc_sin / cos
+    double el, gas, eua;
+    RecFast rec;
+    bool changed;
+};
+
+enum { NOISE_NONE = 0, NOISE_TAPE = 1, NOISE_RNG = 2 };
+
+// Integer state machine (:339-440, :525-757), branch-free.  Returns the record index.
+template <int NOISE>
+__device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
+                                        HotRegs& R, int act, int e, bool& changed)
+{
+    const unsigned f = R.flags;
+    const int s = f & 7, sb = (f >> 4) & 1, su = (f >> 5) & 1, pp = (f >> 6) & 7, fq = (f >> 9) & 7;
+    const unsigned mset = (f >> 15) & 3;
+    const int tkey = (int)(f >> 17);
+    int hot = (f >> 3) & 1;
+    hot = (tkey <= P.key_cold_max) ? 0 : ((tkey >= P.key_hot_min) ? 1 : hot);        // :339-342
+    const int S = P.S, i0 = R.i, j0 = R.j;
+    const int time_op = i0 + j0 * S;
+    // :368-440 dispatch
+    const bool k1 = (act == 0) & (s != 0);          // _standby
+    const bool k2 = (act == 1) & (s != 1);          // _cooldown
+    const bool k3 = (act == 2) & (s <= 1);          // _startup
+    const bool k4 = (act == 3) & (s == 4);          // _partial
+    const bool k5 = (act == 4) & (s == 3);          // _full
+    const bool noisy = k1 | k2 | k3;
+    const int sb_new = (tkey <= P.key_standby_max) ? 1 : 0;
+    const int dest = k1 ? (2 - sb_new) : k3 ? (3 + hot) : k4 ? 5 : 0;   // cooldown 0, standby_up 1, standby_down 2, startup_cold 3, startup_hot 4, op1 5
+    const unsigned li = (unsigned)(dest * P.nT + tkey);
+    const int idx = lds_lut ? (int)lut16[li] : P.argidx[li];
+    int i_noisy = 0;
+    if (__ballot(noisy)) {                           // :584-585 int(max(idx + normal(0, noise), 0))
+        double z = 0.0;
+        if (NOISE == NOISE_TAPE) { if (noisy) z = P.tape[(size_t)e * P.tape_len + ((unsigned)R.nctr % (unsigned)P.tape_len)]; }
+        else if (NOISE == NOISE_RNG) z = noise_draw(P.noise_seed, P.env_offset + e, (unsigned)R.nctr, P.noise_sigma);
+        R.nctr += noisy ? 1 : 0;
+        double x = (double)idx + z;
+        x = (0 > x) ? 0 : x;
+        i_noisy = (int)x;
+    }
+    // _cont (:559-570): the table the env is in
+    const int t_cont = (s == 0) ? (PTG_T_STANDBY_DOWN + sb) : (s == 1) ? PTG_T_COOLDOWN : (s == 2) ? su : (s == 3) ? part_tid(pp) : full_tid(fq);
+    const int t_noisy = k1 ? (PTG_T_STANDBY_DOWN + sb_new) : k2 ? PTG_T_COOLDOWN : hot;     // startup_cold 0 / startup_hot 1
+    int pp_l = 5, fq_l = 1, i_l = 0, j_l = 1;        // ladder results (_partial :627-691, _full :693-757)
+    if (__ballot(k4 | k5)) {
+        const int* lad = L.lad;
+        const int t = time_op;
+        {   // _partial, by full_op
+            const bool a0 = t < lad[LAD_T2_START_F_P];
+            const int T1 = lad[LAD_T1_P_F_P], T2 = lad[LAD_T2_P_F_P], TPF = lad[LAD_T_P_F], T34 = lad[LAD_T34_P_F_P],
+                      T45 = lad[LAD_T45_P_F_P], T5 = lad[LAD_T5_P_F_P];
+            const bool r1 = t < T1, r2 = (T1 < t) & (t < T2), r3 = (T2 < t) & (t < TPF), r4 = (TPF < t) & (t < T34),
+                       r5 = (T34 < t) & (t < T45), r6 = (T45 < t) & (t < T5);
+            const int pp1 = r1 ? 5 : r2 ? 1 : r3 ? 1 : r4 ? 2 : r5 ? 3 : r6 ? 4 : 5;
+            const int i1 = r1 ? lad[LAD_I_FULL] : r2 ? i0 : r3 ? T2 : r4 ? lad[LAD_T3_P_F_P] : r5 ? lad[LAD_T4_P_F_P] : r6 ? T5 : 0;
+            const int j1 = r1 ? lad[LAD_J_FULL] : r2 ? j0 + 1 : 1;
+            pp_l = (fq == 0) ? (a0 ? 0 : 5) : (fq == 1) ? pp1 : 5;
+            if (k4) { i_l = (fq == 0) ? (a0 ? idx : 0) : (fq == 1) ? i1 : 0; j_l = (fq == 1) ? j1 : 1; }
+        }
+        {   // _full, by part_op
+            const bool b0 = t < lad[LAD_T1_START_P_F];
+            const int T1 = lad[LAD_T1_F_P_F], TFP = lad[LAD_T_F_P], T23 = lad[LAD_T23_F_P_F], T34 = lad[LAD_T34_F_P_F],
+                      T45 = lad[LAD_T45_F_P_F], T5 = lad[LAD_T5_F_P_F];
+            const bool q1 = t < T1, q2 = (T1 < t) & (t < TFP), q3 = (TFP < t) & (t < T23), q4 = (T23 < t) & (t < T34),
+                       q5 = (T34 < t) & (t < T45), q6 = (T45 < t) & (t < T5);
+            const int fq1 = q1 ? 1 : q2 ? 2 : q3 ? 2 : q4 ? 3 : q5 ? 4 : q6 ? 5 : 1;
+            const int i1 = q1 ? lad[LAD_I_FULL] : q2 ? i0 : q3 ? lad[LAD_T2_F_P_F] : q4 ? lad[LAD_T3_F_P_F] : q5 ? lad[LAD_T4_F_P_F] : q6 ? T5 : 0;
+            const int j1 = q1 ? lad[LAD_J_FULL] : q2 ? j0 + 1 : 1;
+            fq_l = (pp == 0) ? (b0 ? 0 : 1) : (pp == 5) ? fq1 : 1;
+            if (k5) { i_l = (pp == 5) ? i1 : 0; j_l = (pp == 5) ? j1 : 1; }
+        }
+    }
+    const int pp_n = k3 ? 0 : k4 ? pp_l : pp;
+    const int fq_n = k3 ? 0 : k5 ? fq_l : fq;
+    int s_n = k1 ? 0 : k2 ? 1 : k3 ? 2 : k4 ? 3 : k5 ? 4 : s;
+    int i_n = noisy ? i_noisy : (k4 | k5) ? i_l : i0;
+    int j_n = noisy ? 1 : (k4 | k5) ? j_l : j0 + 1;
+    const int table = noisy ? t_noisy : k4 ? part_tid(pp_l) : k5 ? full_tid(fq_l) : t_cont;
+    const int sb_n = k1 ? sb_new : sb, su_n = k3 ? hot : su;
+    // _perform_sim_step (:525-557) against the virtual table [rows | splice-or-last-row padding]
+    const int2 tm = L.tm[table];
+    const int n = tm.x;
+    const int start = i_n + (j_n - 1) * S;
+    const int over = start + S - n;
+    const bool inside = over < 0;                    // start + S < n
+    const bool is_su = table <= PTG_T_STARTUP_HOT;   // change_operation: startup -> partial load
+    const bool head = over < S;
+    const int r = inside ? start : (is_su ? (head ? start : n) : min(start, n));
+    const bool splice = (!inside) & is_su;
+    s_n = splice ? 3 : s_n;
+    i_n = (splice & head) ? over : i_n;
+    j_n = (splice & head) ? 0 : j_n;
+    changed = (s != s_n);
+    R.i = i_n; R.j = j_n;
+    R.flags = (unsigned)s_n | (hot << 3) | (sb_n << 4) | (su_n << 5) | (pp_n << 6) | (fq_n << 9) | ((unsigned)act << 12) |
+              (mset << 15) | ((unsigned)tkey << 17);
+    return tm.y + r;
+}
+
+// front half of a step: clock (:442-447), market loads, state machine, record gather -- every load of the step in one burst
+template <bool MOD, int NOISE>
+__device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
+                                          HotRegs& R, int act, int e, HotLoads& Q)
+{
+    const unsigned mset = (R.flags >> 15) & 3;
+    const int k1 = R.k + 1;
+    const int secs = k1 * P.sim_step;
+    int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
+    const bool oob = (H + 13 > P.n_hours) | (D + 2 > P.n_days) | (H < 0) | (D < 0);
+    if (__ballot(oob)) {
+        if (oob) { atomicOr(P.err, 2); H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
+    }
+    const unsigned hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u, db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
+    const float* pA = P.pool32;
+#pragma unroll
+    for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<float>(pA + q, hb4);       // uniform (base + q) + one lane offset: merges to dwordx4
+    if (MOD) {
+        const float* pB = P.pool32 + P.off_featB;
+#pragma unroll
+        for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<float>(pB + q, hb4);
+    } else {
+        const float* pG = P.pool32 + P.off_gasn;
+        const float* pU = P.pool32 + P.off_euan;
+        Q.fb[0] = ld_off<float>(pG, db4); Q.fb[1] = ld_off<float>(pG + 1, db4);
+        Q.fb[2] = ld_off<float>(pU, db4); Q.fb[3] = ld_off<float>(pU + 1, db4);
+    }
+    Q.sc = ld_off<float2>(P.pool32 + P.off_sc, (unsigned)(k1 <= P.eps_sim_steps ? k1 : P.eps_sim_steps) * 8u);
+    Q.el = ld_off<double>(P.pool64, hb4 * 2u);
+    Q.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
+    Q.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
+    const int ridx = hot_ints<NOISE>(P, L, lut16, lds_lut, R, act, e, Q.changed);
+    Q.rec = ld_off<RecFast>(P.recf, (unsigned)ridx * 64u);
+}
+
+// back half: reward (:280-334 in its price-linear form) and bookkeeping
+__device__ __forceinline__ float hot_back(const HotParams& P, HotRegs& R, const HotLoads& Q, const double2 setc, int e, bool live)
+{
+    R.flags = (R.flags & 0x1FFFFu) | ((unsigned)Q.rec.tkey << 17);           // Meth_T_cat = op[-1, 1] (:452)
+    double rew = Q.rec.base + Q.rec.ch4 * (setc.x * P.k_chp + P.k_eua * Q.eua) + Q.rec.c_gas * Q.gas - Q.rec.c_el * Q.el;
+    R.cum += rew;
+    rew -= Q.changed ? setc.y : 0.0;                                         // :332 (setc.y = r_0 * penalty, 0 by default)
+    if (P.track_changes) { if (Q.changed && live) P.st_c[e].nchg += 1; }     // lanes past N shadow env N-1: no side effects
+    R.k += 1;
+    return (float)rew;
+}
+
+template <bool FM>
+struct HotRow {                  // observation row addressing: uniform base + 32-bit lane byte offset (feature q adds q * qbytes)
+    char* base; unsigned boff; unsigned qbytes;
+    __device__ __forceinline__ HotRow(float* b, const HotParams& P, int e)
+        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u) {}
+    __device__ __forceinline__ void put(int q, float v) const { st_off<float>(base, boff + (unsigned)q * qbytes, v); }
+};
+
+template <bool FM, bool MOD>
+__device__ __forceinline__ void hot_store_obs(const HotRow<FM>& row, const HotLoads& Q, int s)
+{
+#pragma unroll
+    for (int q = 0; q < 13; q++) row.put(q, Q.fa[q]);
+#pragma unroll
+    for (int q = 0; q < (MOD ? 13 : 4); q++) row.put(13 + q, Q.fb[q]);
+    constexpr int o = MOD ? 26 : 17;
+    row.put(o + 0, (float)s);
+#pragma unroll
+    for (int q = 0; q < 6; q++) row.put(o + 1 + q, Q.rec.feat[q]);
+    row.put(o + 7, Q.sc.x);
+    row.put(o + 8, Q.sc.y);
+}
+
+__device__ __forceinline__ void hot_stage_lds(const HotParams& P, HotLds& L)
+{
+    if (threadIdx.x < NT) L.tm[threadIdx.x] = P.tabmeta[threadIdx.x];
+    else if (threadIdx.x >= 32 && threadIdx.x < 32 + LAD_N) L.lad[threadIdx.x - 32] = P.ladder[threadIdx.x - 32];
+}
+
+// raw action -> action id; an invalid discrete action flags the error word and is replaced by the previous action
+template <int ACTK>
+__device__ __forceinline__ int hot_decode(const HotParams& P, int raw_i, float raw_f, unsigned flags)
+{
+    const int prev = (flags >> 12) & 7;
+    if (ACTK == PTG_ACT_F32) return decode_action(&raw_f, PTG_ACT_F32, 0, prev);
+    const bool bad = (raw_i < -5) | (raw_i > 4);
+    if (__ballot(bad)) { if (bad) atomicOr(P.err, 1); }
+    return bad ? prev : (raw_i < 0 ? raw_i + 5 : raw_i);
+}
+
+template <int ACTK>
+__device__ __forceinline__ void hot_fetch(const void* actions, size_t g, int& ri, float& rf)
+{
+    if (ACTK == PTG_ACT_F32) rf = ((const float*)actions)[g];
+    else if (ACTK == PTG_ACT_I64) { const long long v = ((const long long*)actions)[g]; ri = (v < -5 || v > 4) ? 99 : (int)v; }
+    else ri = ((const int*)actions)[g];
+}
+
+// one vector step, no env terminates (host-guaranteed); lanes past N shadow env N-1 and store nothing
+template <bool FM, bool MOD, int NOISE, int ACTK>
+__global__ void __launch_bounds__(256)
+k_step_hot(const HotParams P, const void* __restrict__ actions, float* __restrict__ obs, float* __restrict__ rew,
+           uint8_t* __restrict__ done)
+{
+    __shared__ HotLds L;
+    const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e_raw < P.N;
+    const int e = live ? e_raw : P.N - 1;
+    const StA a = P.st_a[e]; const StB b = P.st_b[e];     // state + action loads in flight while LDS is staged
+    int ri = 0; float rf = 0.f;
+    hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
+    hot_stage_lds(P, L);
+    __syncthreads();
+    HotRegs R;
+    R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
+    const double2 setc = P.setc[(R.flags >> 15) & 3];
+    const int act = hot_decode<ACTK>(P, ri, rf, R.flags);
+    HotLoads Q;
+    hot_front<MOD, NOISE>(P, L, nullptr, false, R, act, e, Q);
+    const float r = hot_back(P, R, Q, setc, e, live);
+    if (live) {
+        hot_store_obs<FM, MOD>(HotRow<FM>(obs, P, e), Q, R.flags & 7);
+        st_off<float>(rew, (unsigned)e * 4u, r);
+        st_off<uint8_t>(done, (unsigned)e, 0);
+        StA na; na.i = R.i; na.j = R.j; na.k = R.k; na.flags = R.flags;
+        StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
+        P.st_a[e] = na; P.st_b[e] = nb;
+    }
+}
+
+// T fused steps, no env terminates inside (host-guaranteed): state in registers, small tables in LDS, actions fetched two
+// steps ahead, loads of step t+1 issued before the stores of step t
+template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT>
+__global__ void __launch_bounds__(512)
+k_rollout_hot(const HotParams P, const void* __restrict__ actions, int T, float* __restrict__ obs, float* __restrict__ rew,
+              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    HotLds& L = *(HotLds*)s_dyn;
+    unsigned short* s_lut = (unsigned short*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
+    const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e_raw < P.N;
+    const int e = live ? e_raw : P.N - 1;
+    const StA a = P.st_a[e]; const StB b = P.st_b[e];
+    int ri = 0, ni = 0; float rf = 0.f, nf = 0.f;
+    hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
+    if (T > 1) hot_fetch<ACTK>(actions, (size_t)P.N + e, ni, nf);
+    hot_stage_lds(P, L);
+    if (LDSLUT) {
+        const int words = (N_DEST * P.nT + 1) / 2;
+        const unsigned* src = (const unsigned*)lut16;
+        unsigned* dst = (unsigned*)s_lut;
+        for (int q = threadIdx.x; q < words; q += blockDim.x) dst[q] = src[q];
+    }
+    __syncthreads();
+    const unsigned short* lut = LDSLUT ? s_lut : nullptr;
+    HotRegs R;
+    R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
+    const double2 setc = P.setc[(R.flags >> 15) & 3];
+    const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
+    HotLoads Q;
+    hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, Q);      // prologue: front half of step 0
+    char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;
+    for (int t = 0; t < T; t++) {
+        const float r = hot_back(P, R, Q, setc, e, live);   // needs the record of step t
+        const int s_out = R.flags & 7;
+        HotLoads Qn;
+        if (t + 1 < T) {                                    // front half of step t+1 BEFORE the stores of step t
+            const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
+            if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
+            hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, Qn);
+        }
+        if (live) {
+            hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
+            st_off<float>(rew_t, (unsigned)e * 4u, r);
+            st_off<uint8_t>(done_t, (unsigned)e, 0);
+        }
+        obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
+        Q = Qn;
+    }
+    if (live) {
+        StA na; na.i = R.i; na.j = R.j; na.k = R.k; na.flags = R.flags;
+        StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
+        P.st_a[e] = na; P.st_b[e] = nb;
+    }
+}
+
 }  // namespace
 
 // ================================================================================================= host side
@@ -727,9 +1126,13 @@ struct ptg_env {
     size_t rec_total = 0;
     bool fast = false, fm = false;
     double* d_tape = nullptr;
+    unsigned short* d_lut16 = nullptr;
+    float* d_pool32 = nullptr; double* d_pool64 = nullptr;
+    unsigned off_featB = 0, off_gasn = 0, off_euan = 0, off_gas = 0, off_eua = 0, off_sc = 0;
+    std::vector<float> pool32_host;
+    int* d_ladder = nullptr;
+    int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
     int tape_len = 0;
-    unsigned noise_epoch = 0;
-    long long env_offset = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
     int* d_eps_ind = nullptr;
     std::string err;
@@ -864,6 +1267,17 @@ int build_tables(ptg_env* h, const ptg_tables* tb)
     HIP_TRY(h, hipMemcpy(&P.i_reset, d_arg + P.key_init, sizeof(int), hipMemcpyDeviceToHost));
     for (int c = 0; c < 5; c++) P.reset_flow[c] = tb->data_host[PTG_T_COOLDOWN][(size_t)P.i_reset * NC + 2 + c];
     P.T_init = h->cfg.t_cat_initial;
+    {   // uint16 copy of the lookup for LDS residency in k_rollout (every table has < 65536 rows; else stay with int32 in L2)
+        std::vector<int> lut((size_t)N_DEST * nT);
+        HIP_TRY(h, hipMemcpy(lut.data(), d_arg, sizeof(int) * lut.size(), hipMemcpyDeviceToHost));
+        bool fits = true;
+        for (int v : lut) fits = fits && v >= 0 && v < 65536;
+        if (fits) {
+            std::vector<unsigned short> l16(lut.size() + 2, 0);
+            for (size_t q = 0; q < lut.size(); q++) l16[q] = (unsigned short)lut[q];
+            if ((rc = dev_upload(h, &h->d_lut16, l16.data(), l16.size()))) return rc;
+        }
+    }
     (void)hipFree(d_raw); (void)hipFree(d_key);
     return 0;
 }
@@ -915,20 +1329,96 @@ int build_market(ptg_env* h, const ptg_market* sets, int n_sets)
     if ((rc = dev_upload(h, &h->d_pot_raw, pot.data(), pot.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_pf_raw, pf.data(), pf.size()))) return rc;
     if ((rc = dev_upload(h, &d_setc, setc.data(), setc.size()))) return rc;
-    {   // float32 copies of the pre-normalised feature series for the fast path (one rounding of the float64 value)
-        std::vector<float> fa32(fa.begin(), fa.end()), fb32(fb.begin(), fb.end()), g32(gasn.begin(), gasn.end()), e32(euan.begin(), euan.end());
-        float *d_a, *d_b, *d_g, *d_e;
-        if ((rc = dev_upload(h, &d_a, fa32.data(), fa32.size()))) return rc;
-        if ((rc = dev_upload(h, &d_b, fb32.data(), fb32.size()))) return rc;
-        if ((rc = dev_upload(h, &d_g, g32.data(), g32.size()))) return rc;
-        if ((rc = dev_upload(h, &d_e, e32.data(), e32.size()))) return rc;
-        P.featA32 = d_a; P.featB32 = d_b; P.gas_n32 = d_g; P.eua_n32 = d_e;
+    {   // float32 copies of the pre-normalised feature series for the fast path (one rounding of the float64 value),
+        // pooled so that the fast kernels address them as one base pointer + element offsets
+        std::vector<float> pool;
+        pool.insert(pool.end(), fa.begin(), fa.end());
+        h->off_featB = (unsigned)pool.size(); pool.insert(pool.end(), fb.begin(), fb.end());
+        h->off_gasn = (unsigned)pool.size(); pool.insert(pool.end(), gasn.begin(), gasn.end());
+        h->off_euan = (unsigned)pool.size(); pool.insert(pool.end(), euan.begin(), euan.end());
+        h->pool32_host = pool;                            // uploaded by ptg_create once the sin/cos table is appended
+        std::vector<double> p64;
+        p64.insert(p64.end(), el.begin(), el.end());
+        h->off_gas = (unsigned)p64.size(); p64.insert(p64.end(), gas.begin(), gas.end());
+        h->off_eua = (unsigned)p64.size(); p64.insert(p64.end(), eua.begin(), eua.end());
+        double* d_p64;
+        if ((rc = dev_upload(h, &d_p64, p64.data(), p64.size()))) return rc;
+        h->d_pool64 = d_p64;
     }
     P.pot_raw = h->d_pot_raw; P.pf_raw = h->d_pf_raw;
     P.el = d_el; P.featA = d_fa; P.featB = d_fb; P.gas = d_gas; P.eua = d_eua; P.gas_n = d_gasn; P.eua_n = d_euan; P.setc = d_setc;
     P.n_hours = nh; P.n_days = nd; P.hstride = nh; P.dstride = nd;
     return 0;
 }
+
+HotParams make_hot_params(const ptg_env* h)
+{
+    const DevParams& P = h->P;
+    HotParams F;
+    memset(&F, 0, sizeof F);
+    F.N = P.N; F.S = P.S; F.sim_step = P.sim_step; F.eps_sim_steps = P.eps_sim_steps; F.F = P.F; F.nT = P.nT; F.tape_len = P.tape_len;
+    F.track_changes = P.track_changes; F.key_cold_max = P.key_cold_max; F.key_hot_min = P.key_hot_min; F.key_standby_max = P.key_standby_max;
+    F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride; F.dbg = P.dbg;
+    F.off_featB = h->off_featB; F.off_gasn = h->off_gasn; F.off_euan = h->off_euan; F.off_sc = h->off_sc; F.off_gas = h->off_gas; F.off_eua = h->off_eua;
+    F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.noise_sigma = P.noise_sigma; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
+    F.recf = P.recf; F.tape = P.tape; F.pool32 = h->d_pool32; F.pool64 = h->d_pool64; F.setc = P.setc; F.argidx = P.argidx;
+    F.tabmeta = P.tabmeta; F.ladder = h->d_ladder; F.st_a = P.st_a; F.st_b = P.st_b; F.st_c = P.st_c; F.err = P.err;
+    return F;
+}
+
+// the hot kernels apply to float32 outputs, 13-hour look-ahead, a synchronised batch, and steps on which no env terminates
+bool hot_eligible(const ptg_env* h)
+{
+    return h->cfg.out_dtype == PTG_OUT_F32 && h->cfg.price_ahead == 13 && h->sync_k >= 0 && !getenv("PTG_NO_HOT_KERNELS") &&
+           (unsigned long long)h->n * h->F * 4ull < 0xFFFFFFFFull;
+}
+
+int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
+
+template <bool FM, bool MOD, int NOISE>
+void launch_step_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, float* obs, float* rew, uint8_t* done)
+{
+    const HotParams hp = make_hot_params(h);
+    const dim3 grid(grid_for(h->n, 256)), block(256);
+    if (kind == PTG_ACT_F32) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_F32>), grid, block, 0, st, hp, actions, obs, rew, done);
+    else if (kind == PTG_ACT_I64) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I64>), grid, block, 0, st, hp, actions, obs, rew, done);
+    else hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, obs, rew, done);
+}
+
+template <bool FM, bool MOD, int NOISE>
+void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
+{
+    const HotParams hp = make_hot_params(h);
+    int bs = 64;                                            // one lane per env; >= 256 workgroups when the batch allows, <= 512 threads
+    while (bs < 512 && (long long)grid_for(h->n, bs * 2) >= 256) bs *= 2;
+    if (getenv("PTG_BLOCK")) bs = atoi(getenv("PTG_BLOCK"));
+    const dim3 grid(grid_for(h->n, bs)), block(bs);
+    const size_t l_bytes = 16 * ((sizeof(HotLds) + 15) / 16);
+    const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
+    const bool ll = h->d_lut16 && l_bytes + lut_bytes <= 64000 && !getenv("PTG_NO_LDS_LUT");
+    const size_t sh = l_bytes + (ll ? lut_bytes : 0);
+#define PTG_RH(ACTK, LL) hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL>), grid, block, sh, st, hp, actions, T, obs, rew, done, h->d_lut16)
+    if (kind == PTG_ACT_F32) { if (ll) PTG_RH(PTG_ACT_F32, true); else PTG_RH(PTG_ACT_F32, false); }
+    else if (kind == PTG_ACT_I64) { if (ll) PTG_RH(PTG_ACT_I64, true); else PTG_RH(PTG_ACT_I64, false); }
+    else { if (ll) PTG_RH(PTG_ACT_I32, true); else PTG_RH(PTG_ACT_I32, false); }
+#undef PTG_RH
+}
+
+#define PTG_HOT_DISPATCH(FN, ...)                                                                       \
+    do {                                                                                                \
+        const int nm_ = noise_mode(h);                                                                  \
+        const bool fm_ = h->fm, mod_ = h->P.mod != 0;                                                   \
+        if (nm_ == NOISE_TAPE) {                                                                        \
+            if (fm_) { if (mod_) FN<true, true, NOISE_TAPE>(__VA_ARGS__); else FN<true, false, NOISE_TAPE>(__VA_ARGS__); } \
+            else { if (mod_) FN<false, true, NOISE_TAPE>(__VA_ARGS__); else FN<false, false, NOISE_TAPE>(__VA_ARGS__); }   \
+        } else if (nm_ == NOISE_RNG) {                                                                  \
+            if (fm_) { if (mod_) FN<true, true, NOISE_RNG>(__VA_ARGS__); else FN<true, false, NOISE_RNG>(__VA_ARGS__); }   \
+            else { if (mod_) FN<false, true, NOISE_RNG>(__VA_ARGS__); else FN<false, false, NOISE_RNG>(__VA_ARGS__); }     \
+        } else {                                                                                        \
+            if (fm_) { if (mod_) FN<true, true, NOISE_NONE>(__VA_ARGS__); else FN<true, false, NOISE_NONE>(__VA_ARGS__); } \
+            else { if (mod_) FN<false, true, NOISE_NONE>(__VA_ARGS__); else FN<false, false, NOISE_NONE>(__VA_ARGS__); }   \
+        }                                                                                               \
+    } while (0)
 
 hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
@@ -1000,6 +1490,9 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
 
     P.N = n_envs; P.S = h->S; P.sim_step = cfg->sim_step; P.eps_sim_steps = cfg->eps_sim_steps; P.PA = cfg->price_ahead;
     P.F = h->F; P.mod = cfg->raw_modified; P.eps_len_d = cfg->eps_len_d; P.E = 0; P.ep_stride = 0; P.tape_len = 0;
+    P.noise_inline = 0; P.noise_seed = 0; P.env_offset = 0; P.noise_sigma = cfg->noise;
+    P.track_changes = (cfg->state_change_penalty != 0.0) ? 1 : 0;
+    P.dbg = getenv("PTG_DEBUG_FLAGS") ? atoi(getenv("PTG_DEBUG_FLAGS")) : 0;
     P.t1_start_p_f = cfg->time1_start_p_f; P.t2_start_f_p = cfg->time2_start_f_p; P.t_p_f = cfg->time_p_f; P.t_f_p = cfg->time_f_p;
     P.t1_p_f_p = cfg->time1_p_f_p; P.t2_p_f_p = cfg->time2_p_f_p; P.t3_p_f_p = cfg->time3_p_f_p; P.t34_p_f_p = cfg->time34_p_f_p;
     P.t4_p_f_p = cfg->time4_p_f_p; P.t45_p_f_p = cfg->time45_p_f_p; P.t5_p_f_p = cfg->time5_p_f_p; P.t1_f_p_f = cfg->time1_f_p_f;
@@ -1033,6 +1526,16 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         float2* d_sc32;
         if ((rc = dev_upload(h, &d_sc32, sc32.data(), sc32.size()))) return fail(rc);
         P.sincos32 = d_sc32;
+        // pool32 = [featA | featB | gas_n | eua_n | sin,cos pairs]: one base pointer for every float32 lookup of the fast kernels
+        std::vector<float>& pool = h->pool32_host;
+        h->off_sc = (unsigned)pool.size();
+        for (size_t q = 0; q < sc32.size(); q++) { pool.push_back(sc32[q].x); pool.push_back(sc32[q].y); }
+        pool.resize(pool.size() + 16, 0.f);
+        float* d_pool;
+        if ((rc = dev_upload(h, &d_pool, pool.data(), pool.size()))) return fail(rc);
+        h->d_pool32 = d_pool;
+        P.featA32 = d_pool; P.featB32 = d_pool + h->off_featB; P.gas_n32 = d_pool + h->off_gasn; P.eua_n32 = d_pool + h->off_euan;
+        pool.clear(); pool.shrink_to_fit();
     }
     // fast-path records: reward coefficients per window start (k_build_fast)
     {
@@ -1055,6 +1558,12 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     if (hipMemset(P.fin_count, 0, sizeof(int)) != hipSuccess || hipMemset(P.err, 0, sizeof(int)) != hipSuccess) {
         set_err(h, PTG_E_HIP, "hipMemset failed");
         return fail(PTG_E_HIP);
+    }
+    {   // load-change ladder thresholds of the hot kernels (staged into LDS by every workgroup)
+        const int lad[LAD_N] = {P.t1_start_p_f, P.t2_start_f_p, P.t_p_f, P.t_f_p, P.t1_p_f_p, P.t2_p_f_p, P.t3_p_f_p, P.t34_p_f_p, P.t4_p_f_p,
+                                P.t45_p_f_p, P.t5_p_f_p, P.t1_f_p_f, P.t2_f_p_f, P.t23_f_p_f, P.t3_f_p_f, P.t34_f_p_f, P.t4_f_p_f, P.t45_f_p_f,
+                                P.t5_f_p_f, P.i_full, P.j_full};
+        if ((rc = dev_upload(h, &h->d_ladder, lad, LAD_N))) return fail(rc);
     }
     hipLaunchKernelGGL(k_init_state, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, P, 0, 0);
     if ((rc = launch_check(h, "k_init_state"))) return fail(rc);
@@ -1119,6 +1628,7 @@ int ptg_set_noise_tape(ptg_env* h, const double* tape_host, int per_env_len)
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = set_tape_len(h, per_env_len);
     if (rc) return rc;
+    h->P.noise_inline = 0;
     if (per_env_len > 0)
         HIP_TRY(h, hipMemcpy(h->d_tape, tape_host, sizeof(double) * (size_t)h->n * per_env_len, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_zero_noise_count, dim3(grid_for(h->n, 256)), dim3(256), 0, 0, h->P);
@@ -1135,10 +1645,32 @@ int ptg_fill_noise_tape(ptg_env* h, uint64_t seed, int per_env_len, void* stream
     if (rc) return rc;
     const long long total = (long long)h->n * per_env_len;
     hipLaunchKernelGGL(k_fill_noise, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), h->d_tape, h->n, per_env_len,
-                       (unsigned long long)seed, h->noise_epoch++, h->env_offset, h->cfg.noise);
+                       (unsigned long long)seed, h->P.env_offset, h->cfg.noise);
+    h->P.noise_inline = 0; h->P.noise_seed = (unsigned long long)seed;
     if ((rc = launch_check(h, "k_fill_noise"))) return rc;
     hipLaunchKernelGGL(k_zero_noise_count, dim3(grid_for(h->n, 256)), dim3(256), 0, as_stream(stream), h->P);
     return launch_check(h, "k_zero_noise_count");
+}
+
+int ptg_set_noise_rng(ptg_env* h, uint64_t seed)
+{
+    if (!h) return PTG_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    int rc = set_tape_len(h, 0);
+    if (rc) return rc;
+    h->P.noise_inline = 1; h->P.noise_seed = (unsigned long long)seed;
+    hipLaunchKernelGGL(k_zero_noise_count, dim3(grid_for(h->n, 256)), dim3(256), 0, 0, h->P);
+    if ((rc = launch_check(h, "k_zero_noise_count"))) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    return 0;
+}
+
+int ptg_set_global_env_offset(ptg_env* h, int64_t offset)
+{
+    if (!h || offset < 0) return set_err(h, PTG_E_INVALID, "bad env offset");
+    h->P.env_offset = (long long)offset;
+    return 0;
 }
 
 int ptg_get_noise_tape(ptg_env* h, double* tape_host)
@@ -1172,21 +1704,15 @@ int ptg_reset(ptg_env* h, const uint8_t* mask_host, void* obs_dev, void* stream)
     int rc = launch_check(h, "k_reset");
     if (d_mask) { (void)hipStreamSynchronize(st); (void)hipFree(d_mask); }
     if (rc) return rc;
-    if (!mask_host) h->reset_done = true;
+    if (!mask_host) { h->reset_done = true; h->sync_k = 0; }
+    else h->sync_k = -1;                                 // a partial reset de-synchronises the batch
     return 0;
 }
 
-int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev, uint8_t* done_dev,
-             void* final_obs_dev, double* info_dev, void* stream)
+// generic (any configuration, handles termination + auto-reset) launch of one vector step
+static int launch_step_generic(ptg_env* h, hipStream_t st, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev,
+                               uint8_t* done_dev, void* final_obs_dev, double* info_dev)
 {
-    if (!h) return PTG_E_INVALID;
-    if (!actions_dev || !obs_dev || !rew_dev || !done_dev) return set_err(h, PTG_E_INVALID, "ptg_step: null buffer");
-    if (action_kind < PTG_ACT_I32 || action_kind > PTG_ACT_I64) return set_err(h, PTG_E_INVALID, "ptg_step: bad action_kind");
-    if ((h->cfg.action_type == 1) != (action_kind == PTG_ACT_F32))
-        return set_err(h, PTG_E_INVALID, "ptg_step: action_kind does not match cfg.action_type");
-    if (!h->reset_done) return set_err(h, PTG_E_INVALID, "ptg_step: envs must be reset first");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t st = as_stream(stream);
     const dim3 grid(grid_for(h->n, 256)), block(256);
     const bool f64 = h->cfg.out_dtype == PTG_OUT_F64;
 #define PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, PAC)                                                                     \
@@ -1207,6 +1733,54 @@ int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev
     return launch_check(h, "k_step");
 }
 
+static int launch_rollout_generic(ptg_env* h, hipStream_t st, const void* actions_dev, int action_kind, int n_steps, void* obs_dev,
+                                  void* rew_dev, uint8_t* done_dev)
+{
+    // block size: one lane per env, >= 256 workgroups when the batch allows it (one per CU), up to 1024 threads (4 waves/SIMD)
+    int bs = 64;
+    while (bs < 1024 && (long long)grid_for(h->n, bs * 2) >= 256) bs *= 2;
+    const dim3 rgrid(grid_for(h->n, bs)), rblock(bs);
+    const size_t tm_bytes = 16 * ((NT * sizeof(int2) + 15) / 16);
+    const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
+    const bool ldslut = h->d_lut16 && tm_bytes + lut_bytes <= 64000;
+    const size_t shmem = tm_bytes + (ldslut ? lut_bytes : 0);
+#define PTG_LAUNCH_ROLL__(OUT, FAST, FM, PAC, LL)                                                                 \
+    hipLaunchKernelGGL((k_rollout<OUT, FAST, FM, PAC, LL>), rgrid, rblock, shmem, st, h->P, actions_dev, action_kind, n_steps, \
+                       (OUT*)obs_dev, (OUT*)rew_dev, done_dev, h->d_lut16)
+#define PTG_LAUNCH_ROLL_(OUT, FAST, FM, PAC)                                                                      \
+    do { if (ldslut) PTG_LAUNCH_ROLL__(OUT, FAST, FM, PAC, true); else PTG_LAUNCH_ROLL__(OUT, FAST, FM, PAC, false); } while (0)
+#define PTG_LAUNCH_ROLL(OUT, FAST, FM)                                                                           \
+    do { if (h->cfg.price_ahead == 13) PTG_LAUNCH_ROLL_(OUT, FAST, FM, 13); else PTG_LAUNCH_ROLL_(OUT, FAST, FM, 0); } while (0)
+    if (h->cfg.out_dtype == PTG_OUT_F64) { if (h->fm) PTG_LAUNCH_ROLL(double, false, true); else PTG_LAUNCH_ROLL(double, false, false); }
+    else { if (h->fm) PTG_LAUNCH_ROLL(float, true, true); else PTG_LAUNCH_ROLL(float, true, false); }
+#undef PTG_LAUNCH_ROLL
+#undef PTG_LAUNCH_ROLL_
+#undef PTG_LAUNCH_ROLL__
+    return launch_check(h, "k_rollout");
+}
+
+int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev, uint8_t* done_dev,
+             void* final_obs_dev, double* info_dev, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!actions_dev || !obs_dev || !rew_dev || !done_dev) return set_err(h, PTG_E_INVALID, "ptg_step: null buffer");
+    if (action_kind < PTG_ACT_I32 || action_kind > PTG_ACT_I64) return set_err(h, PTG_E_INVALID, "ptg_step: bad action_kind");
+    if ((h->cfg.action_type == 1) != (action_kind == PTG_ACT_F32))
+        return set_err(h, PTG_E_INVALID, "ptg_step: action_kind does not match cfg.action_type");
+    if (!h->reset_done) return set_err(h, PTG_E_INVALID, "ptg_step: envs must be reset first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    const int k_term = h->cfg.eps_sim_steps - 6;               // the step taken at k == k_term terminates (:508-511)
+    if (hot_eligible(h) && !info_dev && h->sync_k != k_term) {
+        PTG_HOT_DISPATCH(launch_step_hot, h, st, actions_dev, action_kind, (float*)obs_dev, (float*)rew_dev, done_dev);
+        h->sync_k += 1;
+        return launch_check(h, "k_step_hot");
+    }
+    const int rc = launch_step_generic(h, st, actions_dev, action_kind, obs_dev, rew_dev, done_dev, final_obs_dev, info_dev);
+    if (h->sync_k >= 0) h->sync_k = (h->sync_k == k_term) ? 0 : h->sync_k + 1;   // a synchronised batch resets together
+    return rc;
+}
+
 int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
                 uint8_t* done_dev, void* stream)
 {
@@ -1218,17 +1792,32 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
     if (!h->reset_done) return set_err(h, PTG_E_INVALID, "ptg_rollout: envs must be reset first");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = as_stream(stream);
-    const dim3 grid(grid_for(h->n, 256)), block(256);
-#define PTG_LAUNCH_ROLL_(OUT, FAST, FM, PAC)                                                                     \
-    hipLaunchKernelGGL((k_rollout<OUT, FAST, FM, PAC>), grid, block, 0, st, h->P, actions_dev, action_kind, n_steps, \
-                       (OUT*)obs_dev, (OUT*)rew_dev, done_dev)
-#define PTG_LAUNCH_ROLL(OUT, FAST, FM)                                                                           \
-    do { if (h->cfg.price_ahead == 13) PTG_LAUNCH_ROLL_(OUT, FAST, FM, 13); else PTG_LAUNCH_ROLL_(OUT, FAST, FM, 0); } while (0)
-    if (h->cfg.out_dtype == PTG_OUT_F64) { if (h->fm) PTG_LAUNCH_ROLL(double, false, true); else PTG_LAUNCH_ROLL(double, false, false); }
-    else { if (h->fm) PTG_LAUNCH_ROLL(float, true, true); else PTG_LAUNCH_ROLL(float, true, false); }
-#undef PTG_LAUNCH_ROLL
-#undef PTG_LAUNCH_ROLL_
-    return launch_check(h, "k_rollout");
+    const int k_term = h->cfg.eps_sim_steps - 6;
+    const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    int t0 = 0;
+    while (t0 < n_steps) {          // hot segments between the (rare) terminating steps; generic kernels for everything else
+        const char* a_t = (const char*)actions_dev + (size_t)t0 * h->n * asz;
+        char* o_t = (char*)obs_dev + (size_t)t0 * h->n * h->F * osz;
+        char* r_t = (char*)rew_dev + (size_t)t0 * h->n * osz;
+        uint8_t* d_t = done_dev + (size_t)t0 * h->n;
+        int rc = 0, cnt;
+        if (hot_eligible(h) && h->sync_k != k_term) {
+            cnt = std::min(n_steps - t0, k_term - h->sync_k);
+            PTG_HOT_DISPATCH(launch_rollout_hot, h, st, a_t, action_kind, cnt, (float*)o_t, (float*)r_t, d_t);
+            rc = launch_check(h, "k_rollout_hot");
+            h->sync_k += cnt;
+        } else if (h->sync_k >= 0) {                            // the terminating step of a synchronised batch
+            cnt = 1;
+            rc = launch_rollout_generic(h, st, a_t, action_kind, 1, o_t, r_t, d_t);
+            h->sync_k = (h->sync_k == k_term) ? 0 : h->sync_k + 1;
+        } else {
+            cnt = n_steps - t0;
+            rc = launch_rollout_generic(h, st, a_t, action_kind, cnt, o_t, r_t, d_t);
+        }
+        if (rc) return rc;
+        t0 += cnt;
+    }
+    return 0;
 }
 
 int ptg_sync(ptg_env* h, void* stream)
@@ -1260,8 +1849,8 @@ int ptg_get_state(ptg_env* h, int field, void* out_host)
         case PTG_F_K: oi[e] = a[e].k; break;
         case PTG_F_ACT_EP_D: oi[e] = b[e].act_d; break;
         case PTG_F_EP_PTR: oi[e] = c[e].epp; break;
-        case PTG_F_NOISE_COUNT: oi[e] = c[e].nctr; break;
-        case PTG_F_N_STATE_CHANGES: oi[e] = b[e].nchg; break;
+        case PTG_F_NOISE_COUNT: oi[e] = b[e].nctr; break;
+        case PTG_F_N_STATE_CHANGES: oi[e] = c[e].nchg; break;
         case PTG_F_CUM_REW: od[e] = b[e].cum; break;
         case PTG_F_METH_STATE: oi[e] = f & 7; break;
         case PTG_F_HOT_COLD: oi[e] = (f >> 3) & 1; break;
@@ -1302,8 +1891,8 @@ int ptg_set_state(ptg_env* h, int field, const void* in_host)
         case PTG_F_EP_PTR:
             if (ii[e] < 0 || (P.E > 0 && ii[e] >= P.E)) return set_err(h, PTG_E_INVALID, "episode pointer out of range");
             c[e].epp = ii[e]; break;
-        case PTG_F_NOISE_COUNT: c[e].nctr = ii[e]; break;
-        case PTG_F_N_STATE_CHANGES: b[e].nchg = ii[e]; break;
+        case PTG_F_NOISE_COUNT: b[e].nctr = ii[e]; break;
+        case PTG_F_N_STATE_CHANGES: c[e].nchg = ii[e]; break;
         case PTG_F_CUM_REW: b[e].cum = id[e]; break;
         case PTG_F_METH_STATE: if (ii[e] < 0 || ii[e] > 4) return set_err(h, PTG_E_INVALID, "bad meth_state"); f = put(f, 0, 7, ii[e]); break;
         case PTG_F_HOT_COLD: f = put(f, 3, 1, ii[e] != 0); break;
@@ -1333,6 +1922,7 @@ int ptg_set_state(ptg_env* h, int field, const void* in_host)
     HIP_TRY(h, hipMemcpy(P.st_a, a.data(), sizeof(StA) * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(P.st_b, b.data(), sizeof(StB) * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(P.st_c, c.data(), sizeof(StC) * n, hipMemcpyHostToDevice));
+    if (field == PTG_F_K) h->sync_k = -1;               // step counts set by hand: no longer known to be synchronised
     return 0;
 }
 

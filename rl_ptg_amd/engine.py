@@ -158,6 +158,13 @@ class HipEngine:
         assert a.ndim == 2 and a.shape[0] == self.n
         self._chk(self._L.ptg_set_noise_tape(self._h, _dp(a), a.shape[1]))
 
+    def set_noise_rng(self, seed):
+        """Draw the state-change noise inside the kernels from the counter-based generator (no tape)."""
+        self._chk(self._L.ptg_set_noise_rng(self._h, int(seed) & (2 ** 64 - 1)))
+
+    def set_global_env_offset(self, offset):
+        self._chk(self._L.ptg_set_global_env_offset(self._h, int(offset)))
+
     def fill_noise_tape(self, seed, per_env_len):
         self._chk(self._L.ptg_fill_noise_tape(self._h, int(seed) & (2 ** 64 - 1), int(per_env_len), self._stream()))
         self.tape_len = int(per_env_len)

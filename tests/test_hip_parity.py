@@ -157,3 +157,91 @@ def test_invalid_discrete_action_is_an_error_not_ub():
     eng.sync()
     assert eng.get_state("current_action").tolist()[0] == 4
     eng.close()
+
+
+def _synthetic_engine(n, scenario=1, operation="OP1", out_dtype="float64", layout="row"):
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=scenario, operation=operation, eps_len_d=32)
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=out_dtype, obs_layout=layout)
+    eng.set_episode_plan(spec.eps_ind, n, n)
+    return spec, eng
+
+
+def _oracle_for(spec, n, tape):
+    m = spec.markets[0]
+    consts = dict(spec.consts, scenario=m["scenario"], rew_l_b=m["rew_l_b"], rew_u_b=m["rew_u_b"], r_0=m["r_0"])
+    ora = H.po.OracleVecEnv(consts, spec.tables, dict(m, eps_ind=None), n)
+    ora.set_noise_tape(tape)
+    return ora
+
+
+def test_device_rng_tape_vs_oracle_and_inline_mode():
+    """N = 4096, uniform-random actions (43 % state changes): the HIP path with a device-generated noise tape equals the
+    oracle fed the same tape, and the in-kernel RNG mode equals the tape mode bit for bit."""
+    n, K, L = 4096, 120, 128
+    spec, e_tape = _synthetic_engine(n)
+    _, e_rng = _synthetic_engine(n)
+    e_tape.fill_noise_tape(seed=77, per_env_len=L)
+    e_rng.set_noise_rng(seed=77)
+    tape = e_tape.get_noise_tape(L)
+    assert abs(tape.mean()) < 0.05 and abs(tape.std() - 10.0) < 0.05          # N(0, noise = 10)
+    ora = _oracle_for(spec, n, tape)
+    o_ref, _ = ora.reset()
+    np.testing.assert_allclose(e_tape.reset().cpu().numpy(), o_ref, rtol=RTOL64, atol=ATOL64)
+    e_rng.reset()
+    rng = np.random.default_rng(3)
+    for t in range(K):
+        a = rng.integers(0, 5, n).astype(np.int32)
+        o1, r1, d1 = e_tape.step(a)
+        o2, r2, d2 = e_rng.step(a)
+        e_tape.sync(); e_rng.sync()
+        o_ref, r_ref, d_ref, _, _ = ora.step(a)
+        np.testing.assert_allclose(o1.cpu().numpy(), o_ref, rtol=RTOL64, atol=ATOL64)
+        np.testing.assert_allclose(r1.cpu().numpy(), r_ref, rtol=RTOL64, atol=ATOL64)
+        assert np.array_equal(d1.cpu().numpy(), d_ref)
+        assert np.array_equal(o1.cpu().numpy(), o2.cpu().numpy()) and np.array_equal(r1.cpu().numpy(), r2.cpu().numpy())
+    ints, f64s = ora.state()
+    for col, name in [(0, "meth_state"), (1, "i"), (2, "j"), (3, "hot_cold"), (4, "standby_tid"), (5, "startup_tid"),
+                      (6, "partial_tid"), (7, "full_tid"), (8, "k"), (9, "current_action")]:
+        assert np.array_equal(e_tape.get_state(name), ints[:, col]), name
+        assert np.array_equal(e_rng.get_state(name), ints[:, col]), name
+    assert np.array_equal(e_tape.get_state("T_cat"), f64s[:, 2])
+    assert e_tape.get_state("noise_count").max() <= L
+    e_tape.close(); e_rng.close(); ora.close()
+
+
+def test_full_size_properties_n65536():
+    """BASELINE.json size (N = 65 536, BS1/OP1): size-independent properties instead of an oracle run.
+    (1) permutation equivariance: env e of a batch stepped with permuted actions/noise streams equals env perm[e];
+    (2) fused rollout == per-step launches; (3) float32 fast path == float64 reference-order path within 2e-7;
+    (4) replicas: envs given identical actions and noise stay identical (checksum of checksums)."""
+    n, K = 65536, 48
+    spec, a64 = _synthetic_engine(n, out_dtype="float64", layout="row")
+    _, a32 = _synthetic_engine(n, out_dtype="float32", layout="feature")
+    _, b32 = _synthetic_engine(n, out_dtype="float32", layout="feature")
+    rng = np.random.default_rng(11)
+    L = 64
+    tape = rng.normal(0, 10, (n, L))
+    acts = rng.integers(0, 5, (K, n)).astype(np.int32)
+    acts[:, : n // 2] = acts[:, :1]                      # first half of the batch: replicas of env 0
+    tape[: n // 2] = tape[0]
+    perm = rng.permutation(n)
+    a64.set_noise_tape(tape); a32.set_noise_tape(tape); b32.set_noise_tape(tape[perm])
+    a64.reset(); a32.reset(); b32.reset()
+    ro, rr, rd = b32.rollout(acts[:, perm])
+    b32.sync()
+    for t in range(K):
+        o64, r64, d64 = a64.step(acts[t])
+        o32, r32, d32 = a32.step(acts[t])
+        a64.sync(); a32.sync()
+        o64n, o32n = o64.cpu().numpy(), a32.rows(o32).cpu().numpy()
+        np.testing.assert_allclose(o32n, o64n, rtol=RTOL32, atol=ATOL32)
+        np.testing.assert_allclose(r32.cpu().numpy(), r64.cpu().numpy(), rtol=RTOL32, atol=1e-6)
+        assert np.array_equal(b32.rows(ro[t]).cpu().numpy(), o32n[perm])           # (1) + (2)
+        assert np.array_equal(rr[t].cpu().numpy(), r32.cpu().numpy()[perm])
+        assert np.array_equal(o32n[: n // 2], np.broadcast_to(o32n[0], (n // 2, o32n.shape[1])))   # (4)
+    for f in INT_FIELDS:
+        v = a32.get_state(f)
+        assert np.array_equal(v, a64.get_state(f)) and np.array_equal(b32.get_state(f), v[perm]), f
+    a64.close(); a32.close(); b32.close()
