@@ -1,0 +1,289 @@
+"""PtGVecEnv: the batched PtG environment behind the Stable-Baselines3 VecEnv surface.
+
+Replaces, for the reference's training loop, the stack  make_vec_env -> Monitor -> DummyVecEnv  around N reference
+`PTGEnv` objects (src/rl_utils.py:448-453, :480-500); it stays wrappable by `VecNormalize(env, norm_obs=False)` and
+usable by `EvalCallback`.  Constructor input is the reference's own env kwargs dict (`Preprocessing.dict_env_kwargs`,
+src/rl_utils.py:337-405) -- the reference's or rl_ptg_amd.prep's.
+
+    env = PtGVecEnv(dict_input, n_envs=6, train_or_eval="train", seed=3654)
+    obs = env.reset()                                  # dict of np.ndarray [N, ...] in the declared float64 spaces
+    obs, rewards, dones, infos = env.step(actions)     # rewards float32 [N], dones bool [N], infos list of N dicts
+
+Semantics kept from the reference stack
+  * envs are stepped "in env order" and a finished env is reset at once: infos[e]["terminal_observation"] holds the last
+    observation, the returned row is the post-reset observation, infos[e]["episode"] = {"r", "l", "t"} (Monitor),
+    infos[e]["TimeLimit.truncated"] = False; `truncated` never occurs (env/ptg_gym_env.py:478-481);
+  * training envs take their episodes from the shared `eps_ind` sequence in the order N reference envs would
+    (constructor + reset consumption, env/ptg_gym_env.py:59-62,490-493);
+  * `train_or_eval="eval"`: infos carry the reference's 24-key dict (env/ptg_gym_env.py:251-278);
+  * `seed(s)`: env e draws its state-change noise from numpy Generator(PCG64(SeedSequence(s + e))) -- the stream Gymnasium
+    gives the reference env -- when noise="numpy" (bit parity, host-generated tape, meant for small N); noise="device"
+    uses the in-kernel counter RNG (statistically equivalent; any N).
+
+Device-side consumers (a policy living on the same GPU) can skip the NumPy hand-off: `step_tensors(actions)` returns the
+ROCm tensors (obs matrix [N, F] or feature-major [F, N], rewards, dones) without synchronising.
+"""
+import time
+
+import numpy as np
+
+from .engine import ACTIONS, HipEngine
+from .prep import EnvSpec
+from .spaces import make_spaces, obs_columns
+
+INFO_KEYS = ["step", "el_price_act", "gas_price_act", "eua_price_act", "Meth_State", "Meth_Action", "Meth_Hot_Cold",
+             "Meth_T_cat", "Meth_H2_flow", "Meth_CH4_flow", "Meth_H2O_flow", "Meth_el_heating", "ch4_revenues [ct/h]",
+             "steam_revenues [ct/h]", "o2_revenues [ct/h]", "eua_revenues [ct/h]", "chp_revenues [ct/h]",
+             "elec_costs_heating [ct/h]", "elec_costs_electrolyzer [ct/h]", "water_costs [ct/h]", "reward [ct]",
+             "cum_reward", "Pot_Reward", "Part_Full"]
+
+try:                                     # pragma: no cover - SB3 is not installed in the build image
+    from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase
+except Exception:
+    _VecEnvBase = object
+
+
+class PtGVecEnv(_VecEnvBase):
+    metadata = {"render_modes": ["None"]}
+
+    def __init__(self, dict_input, n_envs, train_or_eval="train", seed=None, device=0, out_dtype="float64", obs_layout="row",
+                 noise="numpy", noise_tape_len=256, world_size=1, rank=0, render_mode="None", engine_cls=HipEngine):
+        spec = dict_input if isinstance(dict_input, EnvSpec) else EnvSpec.from_dict_input(dict_input, train_or_eval)
+        self.spec = spec
+        self.train_or_eval = train_or_eval
+        self.raw_modified = "mod" if spec.consts["raw_modified"] else "raw"
+        self.action_type = "continuous" if spec.consts["action_type"] else "discrete"
+        self.observation_space, self.action_space = make_spaces(self.raw_modified, self.action_type, spec.consts["price_ahead"])
+        self.num_envs = int(n_envs)
+        self.render_mode = render_mode
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.n_total = self.num_envs * self.world_size
+        self.env_offset = self.num_envs * self.rank
+        if _VecEnvBase is not object:    # pragma: no cover
+            super().__init__(self.num_envs, self.observation_space, self.action_space)
+        self.engine = engine_cls(spec.consts, spec.tables, spec.markets, self.num_envs, device=device, out_dtype=out_dtype,
+                                 obs_layout=obs_layout)
+        self.engine.set_global_env_offset(self.env_offset)
+        # DummyVecEnv order: n_total constructions consume eps_ind[0:n_total]; the first vector reset takes eps_ind[n_total + e]
+        self.engine.set_episode_plan(spec.eps_ind, first_ptr=self.n_total + self.env_offset, stride=self.n_total)
+        self._cols, self._F = obs_columns(self.raw_modified, spec.consts["price_ahead"])
+        self.noise_mode = noise
+        self.noise_sigma = float(spec.consts["noise"])
+        self._tape_len = int(noise_tape_len)
+        self._gens = None
+        self._steps_since_refill = 0
+        self._tape = None
+        self._seed = seed
+        self._apply_seed(seed)
+        self._actions = None
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        self._t0 = time.time()
+        self._ep_start = np.full(self.num_envs, self._t0)
+        self._needs_reset = True
+
+    # ------------------------------------------------------------------ seeding / noise
+    def _apply_seed(self, seed):
+        if self.noise_mode == "device":
+            self.engine.set_noise_rng(0 if seed is None else int(seed))
+            return
+        if self.noise_mode != "numpy":
+            raise ValueError("noise must be 'numpy' or 'device'")
+        # Gymnasium seeding (gymnasium.utils.seeding.np_random): Generator(PCG64(SeedSequence(seed))); None -> OS entropy
+        self._gens = [np.random.Generator(np.random.PCG64(np.random.SeedSequence(None if seed is None else int(seed) + self.env_offset + e)))
+                      for e in range(self.num_envs)]
+        self._tape = np.stack([g.normal(0, self.noise_sigma, size=self._tape_len) for g in self._gens])
+        self.engine.set_noise_tape(self._tape)
+        self._steps_since_refill = 0
+
+    def _refill_tape(self):
+        """At most one draw per env and step is consumed: after tape_len steps move the unread draws to the front and top up."""
+        used = self.engine.get_state("noise_count")
+        L = self._tape_len
+        for e, g in enumerate(self._gens):
+            u = int(min(used[e], L))
+            if u:
+                self._tape[e, :L - u] = self._tape[e, u:]
+                self._tape[e, L - u:] = g.normal(0, self.noise_sigma, size=u)
+        self.engine.set_noise_tape(self._tape)
+        self._steps_since_refill = 0
+
+    def seed(self, seed=None):
+        self._seed = seed
+        self._apply_seed(seed)
+        return [None if seed is None else seed + self.env_offset + e for e in range(self.num_envs)]
+
+    # ------------------------------------------------------------------ observations
+    def _obs_dict(self, mat):
+        """[N, F] float matrix (reference dict order) -> dict keyed like observation_space, dtypes of the declared spaces"""
+        out = {}
+        for k, sl in self._cols.items():
+            if k == "METH_STATUS":
+                out[k] = np.rint(mat[:, sl.start]).astype(np.int64)
+            else:
+                out[k] = np.ascontiguousarray(mat[:, sl], dtype=np.float64)
+        return {k: out[k] for k in self.observation_space.spaces} if hasattr(self.observation_space, "spaces") else out
+
+    def _obs_row_dict(self, row):
+        d = self._obs_dict(row[None, :])
+        return {k: (v[0] if k != "METH_STATUS" else int(v[0])) for k, v in d.items()}
+
+    def _info_dict(self, row):
+        d = {}
+        for q, k in enumerate(INFO_KEYS):
+            v = row[q]
+            if k in ("step", "Meth_State", "Meth_Hot_Cold"):
+                d[k] = int(v)
+            elif k == "Meth_Action":
+                d[k] = ACTIONS[int(v)]
+            else:
+                d[k] = float(v)
+        return d
+
+    # ------------------------------------------------------------------ VecEnv API
+    def reset(self):
+        obs = self.engine.rows(self.engine.reset()).cpu().numpy()
+        self.engine.sync()
+        self._ep_start[:] = time.time()
+        self._needs_reset = False
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        return self._obs_dict(obs)
+
+    def step_async(self, actions):
+        a = np.asarray(actions)
+        if self.action_type == "continuous":
+            a = a.reshape(self.num_envs, -1)[:, 0].astype(np.float32)
+        else:
+            a = a.reshape(self.num_envs).astype(np.int32)
+        self._actions = a
+
+    def step_wait(self):
+        if self._needs_reset:
+            raise RuntimeError("PtGVecEnv: call reset() before step()")
+        eng = self.engine
+        obs_t, rew_t, done_t = eng.step(self._actions)
+        eng.sync()                                            # raises on an invalid action (reference: IndexError)
+        obs = eng.rows(obs_t).cpu().numpy()
+        rews = rew_t.cpu().numpy().astype(np.float32)
+        dones = done_t.cpu().numpy().astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        if eng.info is not None:
+            info = eng.info.cpu().numpy()
+            for e in range(self.num_envs):
+                infos[e] = self._info_dict(info[e])
+        if dones.any():
+            final = eng.rows(eng.final_obs).cpu().numpy()
+            r, l, ids = eng.finished_episodes()
+            now = time.time()
+            ep = {int(i): (float(rr), int(ll)) for rr, ll, i in zip(r, l, ids)}
+            for e in np.nonzero(dones)[0]:
+                infos[e]["terminal_observation"] = self._obs_row_dict(final[e])
+                infos[e]["TimeLimit.truncated"] = False
+                rr, ll = ep.get(int(e), (float("nan"), 0))
+                infos[e]["episode"] = {"r": round(rr, 6), "l": ll, "t": round(now - self._t0, 6)}
+                self._ep_start[e] = now
+        if self.noise_mode == "numpy":
+            self._steps_since_refill += 1
+            if self._steps_since_refill >= self._tape_len:
+                self._refill_tape()
+        return self._obs_dict(obs), rews, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_tensors(self, actions):
+        """Device path: enqueue one step, return (obs, rewards, dones) ROCm tensors without synchronising."""
+        return self.engine.step(actions, want_final=False)
+
+    def close(self):
+        self.engine.close()
+
+    def get_attr(self, attr_name, indices=None):
+        n = len(self._indices(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        raise NotImplementedError(f"PtGVecEnv holds no per-env Python objects (env_method {method_name!r})")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(self._indices(indices))
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode=None):
+        return None
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+
+class PTGEnv:
+    """Single-env Gymnasium-style adapter (the reference's env/ptg_gym_env.py:23 surface) over an N = 1 batch.
+
+    `reset(seed=None, options=None) -> (obs, info)`, `step(action) -> (obs, reward, terminated, truncated, info)`.
+    One reference env in a fresh process: its constructor takes eps_ind[0], every reset the next entry.  The kernels reset a
+    finished env themselves, so the reset() that follows a terminated step hands out that already-prepared episode.
+    """
+    metadata = {"render_modes": ["None"]}
+
+    def __init__(self, dict_input, train_or_eval="train", render_mode="None", device=0, noise="numpy"):
+        assert train_or_eval in ["train", "eval"], 'ptg_gym_env.py error: train_or_eval must be either "train" or "eval".'
+        spec = EnvSpec.from_dict_input(dict_input, "eval")      # info rows are always available to the adapter
+        self._vec = PtGVecEnv(spec, 1, train_or_eval="eval", device=device, noise=noise)
+        self._vec.engine.set_episode_plan(spec.eps_ind, first_ptr=1, stride=1)
+        self.train_or_eval = train_or_eval
+        self.render_mode = render_mode
+        self.observation_space, self.action_space = self._vec.observation_space, self._vec.action_space
+        self._pending = None
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self._vec.seed(seed)
+        if self._pending is not None and seed is None:
+            obs, self._pending = self._pending, None
+        else:
+            self._pending = None
+            obs = {k: (v[0] if k != "METH_STATUS" else int(v[0])) for k, v in self._vec.reset().items()}
+        return obs, self._reset_info()
+
+    def _reset_info(self):
+        """_get_info() of a freshly reset env (env/ptg_gym_env.py:251-278, :105-138): zero revenue terms, flows of the single
+        cooldown row the env starts in."""
+        eng, spec = self._vec.engine, self._vec.spec
+        m = spec.markets[0]
+        d = int(eng.get_state("act_ep_d")[0])
+        row = spec.tables["cooldown"][int(eng.get_state("i")[0])]
+        return {"step": 0, "el_price_act": float(m["el"][d * 24]), "gas_price_act": float(m["gas"][d]), "eua_price_act": float(m["eua"][d]),
+                "Meth_State": int(eng.get_state("meth_state")[0]), "Meth_Action": ACTIONS[int(eng.get_state("current_action")[0])],
+                "Meth_Hot_Cold": int(eng.get_state("hot_cold")[0]), "Meth_T_cat": float(eng.get_state("T_cat")[0]),
+                "Meth_H2_flow": float(row[2]), "Meth_CH4_flow": float(row[3]), "Meth_H2O_flow": float(row[5]), "Meth_el_heating": float(row[6]),
+                "ch4_revenues [ct/h]": 0.0, "steam_revenues [ct/h]": 0.0, "o2_revenues [ct/h]": 0.0, "eua_revenues [ct/h]": 0.0,
+                "chp_revenues [ct/h]": 0.0, "elec_costs_heating [ct/h]": -0.0, "elec_costs_electrolyzer [ct/h]": -0.0,
+                "water_costs [ct/h]": -0.0, "reward [ct]": 0.0, "cum_reward": 0, "Pot_Reward": float(m["pot_rew"][d * 24]),
+                "Part_Full": float(m["part_full"][d * 24])}
+
+    def step(self, action):
+        a = np.asarray(action).reshape(-1)[:1]
+        obs, rew, done, infos = self._vec.step(a)
+        info = infos[0]
+        terminated = bool(done[0])
+        row = {k: (v[0] if k != "METH_STATUS" else int(v[0])) for k, v in obs.items()}
+        if terminated:
+            self._pending = row
+            row = info.pop("terminal_observation")
+            info.pop("episode", None)
+            info.pop("TimeLimit.truncated", None)
+        if self.train_or_eval == "train":
+            info = {}
+        return row, float(rew[0]), terminated, False, info
+
+    def close(self):
+        self._vec.close()

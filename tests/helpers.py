@@ -73,3 +73,18 @@ def make_engine(case, out_dtype="float64", n_envs=None, obs_layout="row"):
         # DummyVecEnv order: n constructions consume eps_ind[0:n], the first vector reset takes eps_ind[n + e]
         eng.set_episode_plan(market["eps_ind"], first_ptr=n, stride=n)
     return tr, eng
+
+
+def kwargs_from_fixture(case):
+    """A reference-style env kwargs dict (src/rl_utils.py:337-405, price data as 1-D series) rebuilt from a trajectory fixture."""
+    tr, consts, tables, market = load_traj(case)
+    kw = {k: v for k, v in consts.items() if k not in ("raw_modified", "action_type", "train_or_eval", "r_0")}
+    kw.update(raw_modified="mod" if consts["raw_modified"] else "raw",
+              action_type="continuous" if consts["action_type"] else "discrete",
+              reward_level=np.array([consts["r_0"]]), parallel="Singleprocessing", n_eps_loops=0,
+              eps_ind=None if market["eps_ind"] is None else market["eps_ind"].astype(int),
+              el_series=market["el"], pot_rew_series=market["pot_rew"], part_full_series=market["part_full"],
+              gas_series=market["gas"], eua_series=market["eua"])
+    kw.update({f"ptg_{k}": i for i, k in enumerate(["standby", "cooldown", "startup", "partial_load", "full_load"])})
+    kw.update(tables)
+    return tr, kw

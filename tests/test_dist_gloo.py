@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: world_size-2 gloo process group.  Sharding arithmetic, the episode plan against the oracle's shared
+ep_index order, and the one collective (all-gather of finished-episode returns) with ragged per-rank counts."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+from rl_ptg_amd import dist as ptg_dist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank r finished r + 2 episodes (ragged): returns r*100 + i, lengths 10 + i
+        r = np.array([rank * 100.0 + i for i in range(rank + 2)])
+        l = np.array([10 + i for i in range(rank + 2)])
+        ra, la = ptg_dist.all_gather_finished(r, l)
+        # the oracle stands in for the GPU engine: shard `rank` of a 6-env batch, episode order of the shared ep_index
+        case = "synth_bs2_op2_term_penalty"
+        tr, consts, tables, market = H.load_traj(case)
+        n_total, n = 6, 3
+        lo, hi = ptg_dist.shard_range(n_total, world, rank)
+        first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
+        env = H.po.OracleVecEnv(consts, tables, market, n, ep_index0=first_ptr - n)   # constructor consumes n, reset the next n
+        env.reset()
+        ints, _ = env.state()
+        q.put((rank, ra.tolist(), la.tolist(), ints[:, 11].tolist(), (lo, hi), (first_ptr, stride)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    exp_r = [0.0, 1.0, 100.0, 101.0, 102.0]
+    for rank, ra, la, act_d, rng, plan in out:
+        assert ra == exp_r and la == [10, 11, 10, 11, 12]
+        assert rng == (rank * 3, rank * 3 + 3) and plan == (6 + rank * 3, 6)
+    # the episode every shard env starts in == what 6 reference envs sharing ep_index get (constructor 0..5, reset 6..11)
+    tr, consts, tables, market = H.load_traj("synth_bs2_op2_term_penalty")
+    full = H.po.OracleVecEnv(consts, tables, market, 6)
+    full.reset()
+    ints, _ = full.state()
+    assert out[0][3] + out[1][3] == ints[:, 11].tolist()
+    assert ints[:, 11].tolist() == (market["eps_ind"][6:12] * consts["eps_len_d"]).astype(int).tolist()
+
+
+def test_shard_helpers():
+    assert ptg_dist.shard_range(524288, 8, 3) == (196608, 262144)
+    assert ptg_dist.episode_plan(524288, 8, 3) == (524288 + 196608, 524288)
+    with pytest.raises(ValueError):
+        ptg_dist.shard_range(10, 4, 0)
+    a = ptg_dist.mixed_scenario_assignment(12, 2, 1, 3)
+    assert a.tolist() == [0, 1, 2, 0, 1, 2] and a.dtype == np.uint8
+    r, l = ptg_dist.all_gather_finished([1.0, 2.0], [3, 4])        # no process group: identity
+    assert r.tolist() == [1.0, 2.0] and l.tolist() == [3, 4]

@@ -245,3 +245,51 @@ def test_full_size_properties_n65536():
         v = a32.get_state(f)
         assert np.array_equal(v, a64.get_state(f)) and np.array_equal(b32.get_state(f), v[perm]), f
     a64.close(); a32.close(); b32.close()
+
+
+def test_sharded_engines_equal_one_batch():
+    """Two shards (rank 0 / 1 of world_size 2, here on one GPU) == one engine over all envs: episode plan over the shared
+    eps_ind order, RNG streams keyed by the global env index, mixed business scenarios per env (BASELINE.json config 5)."""
+    from rl_ptg_amd import dist as ptg_dist
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import EnvSpec, synthetic_spec
+    specs = [synthetic_spec(scenario=sc, operation="OP2", eps_len_d=2, train_steps=40000)[0] for sc in (1, 2, 3)]
+    spec = EnvSpec.merge_scenarios(specs)
+    n_total, world = 512, 2
+    n = n_total // world
+    K = 300                                               # 2-day episodes: 283 steps -> every env terminates once
+
+    def make(n_envs, rank, ws):
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n_envs, device=0, out_dtype="float32", obs_layout="feature")
+        first_ptr, stride = ptg_dist.episode_plan(n_total, ws, rank)
+        eng.set_global_env_offset(first_ptr - n_total)
+        eng.set_market_assignment(ptg_dist.mixed_scenario_assignment(n_total, ws, rank, 3))
+        eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
+        eng.set_noise_rng(99)
+        eng.reset()
+        return eng
+
+    full, s0, s1 = make(n_total, 0, 1), make(n, 0, 2), make(n, 1, 2)
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 5, (K, n_total)).astype(np.int32)
+    of, rf, df = full.rollout(acts)
+    o0, r0, d0 = s0.rollout(acts[:, :n])
+    o1, r1, d1 = s1.rollout(acts[:, n:])
+    full.sync(); s0.sync(); s1.sync()
+    assert int(df.sum()) == n_total                      # each env finished exactly one episode
+    assert np.array_equal(of[:, :, :n].cpu().numpy(), o0.cpu().numpy()) and np.array_equal(of[:, :, n:].cpu().numpy(), o1.cpu().numpy())
+    assert np.array_equal(rf[:, :n].cpu().numpy(), r0.cpu().numpy()) and np.array_equal(rf[:, n:].cpu().numpy(), r1.cpu().numpy())
+    assert np.array_equal(df[:, n:].cpu().numpy(), d1.cpu().numpy())
+    for f in INT_FIELDS + ["act_ep_d", "market_set"]:
+        assert np.array_equal(full.get_state(f), np.concatenate([s0.get_state(f), s1.get_state(f)])), f
+    # episodic returns: the per-shard lists, gathered, are the batch's list
+    rF, lF, iF = full.finished_episodes()
+    rA, lA, iA = s0.finished_episodes()
+    rB, lB, iB = s1.finished_episodes()
+    got = sorted(zip(np.concatenate([iA, iB + n]).tolist(), np.concatenate([rA, rB]).tolist()))
+    assert got == sorted(zip(iF.tolist(), rF.tolist())) and len(got) == n_total
+    assert set(np.concatenate([lA, lB]).tolist()) == {283}
+    # scenario mix actually differs: BS3 envs (gas = EUA = 0, CHP revenue) earn differently from BS1 / BS2 envs
+    ms = full.get_state("market_set")
+    assert len({round(float(np.mean(rF[np.argsort(iF)][ms == q])), 3) for q in range(3)}) == 3
+    full.close(); s0.close(); s1.close()
