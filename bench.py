@@ -38,7 +38,7 @@ def algorithmic_bytes_per_env_step(obs_dim, out_bytes, path):
     return action + 2 * state + out
 
 
-def cpu_baseline(spec, n_envs=4096, n_steps=600, seed=7):
+def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
     """Oracle (CPU restatement of the reference, oracle/ptg_oracle.c) timed on this host's cores: bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ptg_oracle as po
@@ -75,7 +75,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--path", choices=["step", "rollout"], default="step")
+    ap.add_argument("--path", choices=["step", "rollout"], default="step", help="timed path; the other one is measured too (--no-also to skip)")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step path: replay the K launches as one hipGraph, or launch eagerly")
+    ap.add_argument("--no-also", dest="also", action="store_false")
     ap.add_argument("--scenario", type=int, default=1)
     ap.add_argument("--operation", default="OP1")
     ap.add_argument("--out-dtype", choices=["float32", "float64"], default="float32")
@@ -110,70 +112,99 @@ def main():
     K, W, n = args.steps, args.warmup, args.envs
     n_total = n * world
     spec, _ = synthetic_spec(scenario=args.scenario, operation=args.operation, eps_len_d=32)
-    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
     first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
-    eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
-    eng.set_global_env_offset(first_ptr - n_total)
-    if args.noise == "rng":
-        eng.set_noise_rng(seed=20250614)                  # counter-based draws inside the kernels
-    else:
-        eng.fill_noise_tape(seed=20250614, per_env_len=min(max(K + W + 8, 64), 1024))
-    actions = sticky_actions_device(K + W, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
-    eng.reset()
+    F = None
 
-    if args.path == "rollout":
+    def measure(path, launch):
+        """W warm-up steps, then exactly K timed steps of `path`; returns (wall seconds, device ms, finished episodes)."""
+        nonlocal F
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
         F = eng.obs_dim
-        oshape = (max(K, W, 1), F, n) if args.obs_layout == "feature" else (max(K, W, 1), n, F)
-        obs_buf = torch.empty(oshape, dtype=eng.out_dtype, device=device)
-        rew_buf = torch.empty((max(K, W, 1), n), dtype=eng.out_dtype, device=device)
-        done_buf = torch.empty((max(K, W, 1), n), dtype=torch.uint8, device=device)
-
-    def run(t0, cnt):
-        if cnt <= 0:
-            return
-        if args.path == "rollout":
-            eng.rollout(actions[t0:t0 + cnt], obs_buf[:cnt], rew_buf[:cnt], done_buf[:cnt])
+        eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
+        eng.set_global_env_offset(first_ptr - n_total)
+        if args.noise == "rng":
+            eng.set_noise_rng(seed=20250614)                  # counter-based draws inside the kernels
         else:
-            for t in range(t0, t0 + cnt):
-                eng.step(actions[t], want_final=False)
+            eng.fill_noise_tape(seed=20250614, per_env_len=min(max(K + W + 8, 64), 1024))
+        actions = sticky_actions_device(K + W, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
+        eng.reset()
+        bufs = None
+        if path == "rollout":
+            oshape = (max(K, W, 1), F, n) if args.obs_layout == "feature" else (max(K, W, 1), n, F)
+            bufs = (torch.empty(oshape, dtype=eng.out_dtype, device=device), torch.empty((max(K, W, 1), n), dtype=eng.out_dtype, device=device),
+                    torch.empty((max(K, W, 1), n), dtype=torch.uint8, device=device))
 
-    run(0, W)
-    eng.sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    ev0.record()
-    run(W, K)
-    ev1.record()
-    r, l, _ = eng.finished_episodes()          # synchronises; episodic-return reduction (one all-gather, off the step path)
-    r_all, l_all = ptg_dist.all_gather_finished(r, l, device=device)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    eng.sync()
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(tmax[0]), float(tmax[1])
+        def run(t0, cnt):
+            if cnt <= 0:
+                return
+            if path == "rollout":
+                eng.rollout(actions[t0:t0 + cnt], bufs[0][:cnt], bufs[1][:cnt], bufs[2][:cnt])
+            else:
+                for t in range(t0, t0 + cnt):
+                    eng.step(actions[t], want_final=False)
+
+        run(0, W)
+        eng.sync()
+        graph = None
+        if path == "step" and launch == "graph":                # K ptg_step launches captured once, replayed as one hipGraph
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    run(W, K)
+            torch.cuda.current_stream(device).wait_stream(side)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            run(W, K)
+        ev1.record()
+        r, l, _ = eng.finished_episodes()          # synchronises; episodic-return reduction (one all-gather, off the step path)
+        r_all, l_all = ptg_dist.all_gather_finished(r, l, device=device)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        eng.sync()
+        dev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed, dev_ms = float(tmax[0]), float(tmax[1])
+        eng.close()
+        return elapsed, dev_ms, len(r_all)
+
+    def roofline(path, dev_ms, out_bytes):
+        b_alg = algorithmic_bytes_per_env_step(F, out_bytes, path)
+        launches = 1 if path == "rollout" else K
+        per_launch_s = dev_ms * 1e-3 / launches
+        bytes_per_launch = b_alg * n * (K if path == "rollout" else 1)
+        achieved = bytes_per_launch / per_launch_s / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None, "kernel": "k_step_hot" if path == "step" else "k_rollout_hot",
+                "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches}
+
+    elapsed, dev_ms, n_fin = measure(args.path, args.launch)
+    other = "rollout" if args.path == "step" else "step"
+    o_elapsed, o_dev_ms, _ = measure(other, args.launch) if args.also else (None, None, None)
 
     if rank == 0:
         out_bytes = 4 if args.out_dtype == "float32" else 8
-        b_alg = algorithmic_bytes_per_env_step(eng.obs_dim, out_bytes, args.path)
-        launches = 1 if args.path == "rollout" else K
-        per_launch_s = dev_ms * 1e-3 / launches
-        bytes_per_launch = b_alg * n * (K if args.path == "rollout" else 1)
-        achieved = bytes_per_launch / per_launch_s / 1e9
-        traffic = None
+        roof = roofline(args.path, dev_ms, out_bytes)
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.path}_bytes_per_launch")
+                roof["traffic"] = json.load(open(tpath)).get(f"{args.path}_bytes_per_launch")
             except Exception:
-                traffic = None
+                pass
+        path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
+                     "rollout": "ptg_rollout, K steps fused in one launch"}
         line = {
             "metric": "env-steps/sec at N=65536 envs; achieved HBM GB/s vs roofline",
             "value": n_total * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -181,19 +212,17 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} envs/GPU, BS{args.scenario}/{args.operation}, synthetic 38-day trace (32-day episodes), "
                                    f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), noise: {args.noise}",
-                       "path": "ptg_step (one launch per vector step)" if args.path == "step" else "ptg_rollout (K steps fused in one launch)",
-                       "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype, "obs_dim": eng.obs_dim, "obs_layout": args.obs_layout,
-                       "parallelism": f"env-sharded x{world}, no per-step collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "k_step" if args.path == "step" else "k_rollout",
-                         "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6,
-                         "launches_timed": launches},
-            "finished_episodes_gathered": int(len(r_all)),
+                       "path": path_name[args.path], "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype,
+                       "obs_dim": F, "obs_layout": args.obs_layout, "parallelism": f"env-sharded x{world}, no per-step collective"},
+            "roofline": roof,
+            "finished_episodes_gathered": int(n_fin),
         }
+        if o_elapsed is not None:
+            line["also"] = {"path": path_name[other], "value": n_total * K / o_elapsed, "unit": "env-steps/s",
+                            "ms_per_step": o_elapsed * 1e3 / K, "roofline": roofline(other, o_dev_ms, out_bytes)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 
