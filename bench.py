@@ -200,7 +200,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                roof["traffic"] = json.load(open(tpath)).get(f"{args.path}_bytes_per_launch")
+                tj = json.load(open(tpath))          # measured with rocprofv3 PMC passes (profiles/*_summary.md), per launch like `achieved`
+                roof["traffic"] = tj.get("step_bytes_per_launch") if args.path == "step" else tj.get("rollout_bytes_per_step", 0) * K
             except Exception:
                 pass
         path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
