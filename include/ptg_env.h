@@ -131,7 +131,8 @@ int ptg_set_episode_plan(ptg_env* env, const double* eps_ind_host, int n, int64_
  * Host tape (e.g. numpy Generator.normal(0, noise) per env for bit parity with the reference) ... */
 int ptg_set_noise_tape(ptg_env* env, const double* tape_host, int per_env_len);
 /* ... or the device's counter-based generator: the c-th draw of the env with GLOBAL index g is
- *   noise(seed, g, c) = cfg.noise * BoxMuller(Philox4x32-10(key = seed, counter = (c, g)))   (float32 Box-Muller, native log/cos).
+ *   noise(seed, g, c) = cfg.noise * BoxMuller(u1, u2),  (u1, u2) from three rounds of the 32-bit integer finaliser "lowbias32"
+ *   keyed by (seed, g, c); Box-Muller in float32 with the native log / cos.
  * ptg_set_noise_rng draws it inside the step kernels (no tape, unbounded); ptg_fill_noise_tape writes the first per_env_len
  * draws of the same streams to the tape (so both modes give identical trajectories while the tape does not wrap).
  * Both reset the per-env draw counters.  Statistically equivalent to, not bit-equal with, NumPy's Generator.normal. */
@@ -179,6 +180,7 @@ int ptg_finished_episodes(ptg_env* env, double* returns_host, int32_t* lengths_h
 /* diagnostics for tests: the device-built lookup products */
 int ptg_debug_get_index_lut(ptg_env* env, double* T_values_host, int32_t* lut_host /*[6][nT]*/, int* n_T);
 int ptg_debug_window_record(ptg_env* env, int table_id, int start_row, double* out7_host /*T_last, 5 means, key*/);
+int ptg_debug_read_counters(ptg_env* env, long long* out64_host);   /* per-phase cycle sums written by PTG_DEBUG_FLAGS=16 builds */
 
 #ifdef __cplusplus
 }

@@ -227,21 +227,28 @@ __device__ __forceinline__ void store_regs(const DevParams& P, int e, const Regs
     if (R.c_dirty) P.st_c[e] = R.c;
 }
 
+// :351-355: prob_thre[ival] = -1 + ival*0.4 in float64 (:151-155); the first threshold > action picks actions[ival-1]
+// (python index -1 = full_load); no threshold fires (a >= 1, NaN) -> the previous action stays
+__device__ __forceinline__ int decode_continuous(float af, int previous)
+{
+    const double a = (double)af;
+    const double ival = (1.0 - (-1.0)) / 5;
+    int out = previous;
+    bool hit = false;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const double thr = -1.0 + q * ival;
+        const bool fire = (!hit) & (thr > a);
+        out = fire ? ((q == 0) ? 4 : q - 1) : out;
+        hit = hit | fire;
+    }
+    return out;
+}
+
 // :346-357 -> action id 0..4, or -1 for an invalid discrete action
 __device__ __forceinline__ int decode_action(const void* actions, int kind, size_t idx, int previous)
 {
-    if (kind == PTG_ACT_F32) {
-        // prob_thre[ival] = -1 + ival*0.4 in float64 (:151-155); first threshold > action picks actions[ival-1] (:351-355)
-        const double a = (double)((const float*)actions)[idx];
-        const double ival = (1.0 - (-1.0)) / 5;
-        int out = previous;
-        bool hit = false;
-        for (int q = 0; q < 6; q++) {
-            double thr = -1.0 + q * ival;
-            if (!hit && thr > a) { out = (q == 0) ? 4 : q - 1; hit = true; }
-        }
-        return out;
-    }
+    if (kind == PTG_ACT_F32) return decode_continuous(((const float*)actions)[idx], previous);
     long long a = (kind == PTG_ACT_I64) ? ((const long long*)actions)[idx] : (long long)((const int*)actions)[idx];
     if (a < -5 || a > 4) return -1;
     return (int)(a < 0 ? a + 5 : a);      // python list indexing: actions[-1] is full_load
@@ -252,11 +259,6 @@ struct LutGlobal {            // _get_index lookup [6][nT] int32
     const int* p; int nT;
     __device__ __forceinline__ int get(int dest, int tkey) const { return p[dest * nT + tkey]; }
 };
-struct LutLds {               // the same as uint16 in LDS (every table has < 65536 rows)
-    const unsigned short* p; int nT;
-    __device__ __forceinline__ int get(int dest, int tkey) const { return (int)p[dest * nT + tkey]; }
-};
-
 // Integer state machine of step() (:339-440) and _perform_sim_step (:525-557).  Returns the record index.
 // The two memory lookups a state change needs (_get_index entry, noise draw) are issued BEFORE the branchy part so
 // that they overlap; the branches then hold integer arithmetic only.
@@ -632,70 +634,6 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
     push_finished(P, live && term, e, ret, len);
 }
 
-// T fused steps: state in registers, table meta + (when it fits, LDSLUT) the uint16 _get_index lookup in LDS, next action
-// prefetched.  One lane per env; block size is chosen by the host so that >= 256 workgroups exist (one per CU).
-template <typename OUT, bool FAST, bool FM, int PAC, bool LDSLUT>
-__global__ void __launch_bounds__(1024)
-k_rollout(const DevParams P, const void* __restrict__ actions, int action_kind, int T, OUT* __restrict__ obs,
-          OUT* __restrict__ rew, uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    int2* s_tm = (int2*)s_dyn;                                     // [NT]  (aligned(16): Guideline 17)
-    unsigned short* s_lut = (unsigned short*)(s_dyn + 16 * ((NT * sizeof(int2) + 15) / 16));
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = e < P.N;
-    Regs R;
-    if (live) load_regs(P, e, R);
-    if (threadIdx.x < NT) s_tm[threadIdx.x] = P.tabmeta[threadIdx.x];
-    if (LDSLUT) {
-        const int words = (N_DEST * P.nT + 1) / 2;                 // copy as 32-bit words
-        const unsigned* src = (const unsigned*)lut16;
-        unsigned* dst = (unsigned*)s_lut;
-        for (int q = threadIdx.x; q < words; q += blockDim.x) dst[q] = src[q];
-    }
-    __syncthreads();
-    bool bad = false;
-    const size_t NF = (size_t)P.N * P.F;
-    int act_raw = 0; float act_f = 0.f;
-    auto fetch = [&](int t) {                                       // raw action of step t (decoded when used)
-        const size_t g = (size_t)t * P.N + e;
-        if (action_kind == PTG_ACT_F32) act_f = ((const float*)actions)[g];
-        else if (action_kind == PTG_ACT_I64) { long long v = ((const long long*)actions)[g]; act_raw = (v < -5 || v > 4) ? 99 : (int)v; }
-        else act_raw = ((const int*)actions)[g];
-    };
-    if (live) fetch(0);
-    for (int t = 0; t < T; t++) {
-        bool term = false;
-        double ret = 0.0;
-        int len = 0;
-        if (live && !bad) {
-            const size_t g = (size_t)t * P.N + e;
-            const int act = (action_kind == PTG_ACT_F32) ? decode_action(&act_f, PTG_ACT_F32, 0, (R.a.flags >> 12) & 7)
-                                                          : decode_action(&act_raw, PTG_ACT_I32, 0, 0);
-            if (t + 1 < T) fetch(t + 1);
-            if (act < 0) {
-                atomicOr(P.err, 1);
-                bad = true;
-            } else {
-                const ObsRow<OUT, FM> row((P.dbg & 1) ? nullptr : obs + (size_t)t * NF, P, e);
-                OUT r;
-                if (LDSLUT) term = env_step<OUT, FAST, false, FM, PAC>(P, s_tm, LutLds{s_lut, P.nT}, R, e, act, row, &r, nullptr);
-                else term = env_step<OUT, FAST, false, FM, PAC>(P, s_tm, LutGlobal{P.argidx, P.nT}, R, e, act, row, &r, nullptr);
-                rew[g] = r;
-                done[g] = term ? 1 : 0;
-                if (term) {
-                    ret = R.b.cum;
-                    if (P.track_changes) { need_c(P, e, R); ret -= (double)R.c.nchg * P.setc[(R.a.flags >> 15) & 3].y; }
-                    len = R.a.k;
-                    reset_env<OUT, FAST, FM, PAC>(P, R, e, row);
-                }
-            }
-        }
-        push_finished(P, live && term, e, ret, len);
-    }
-    if (live) store_regs(P, e, R);
-}
-
 template <typename OUT, bool FAST, bool FM, int PAC>
 __global__ void k_reset(const DevParams P, const uint8_t* __restrict__ mask, OUT* __restrict__ obs)
 {
@@ -811,6 +749,7 @@ struct HotParams {
     const int* ladder;                                // [LAD_N]
     StA* st_a; StB* st_b; StC* st_c;
     int* err;
+    long long* dbg_out;                               // timing experiments (PTG_DEBUG_FLAGS & 16): per-phase cycle sums of block 0
 };
 
 struct HotLds {                  // per-workgroup LDS image
@@ -828,6 +767,7 @@ struct HotRegs {                 // per-env state in registers
 struct HotLoads {                // everything front() fetched for one step
     float fa[13], fb[13];        // Pot_Reward, Part_Full ('raw': Elec_Price; Gas_Price[2], EUA_Price[2] in fb[0..3])
     float2 sc;                   // Temp_hour_enc_sin / cos
+    unsigned hb4, db4, kk8;      // byte offsets of the step's hour / day / step-count entries in the pools
     double el, gas, eua;
     RecFast rec;
     bool changed;
@@ -929,33 +869,43 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
 }
 
 // front half of a step: clock (:442-447), market loads, state machine, record gather -- every load of the step in one burst
-template <bool MOD, int NOISE>
+// market + clock features of one step: 13 + 13 (or 13 + 4) + 2 float32 loads, merged by the backend into dwordx4
+template <bool MOD>
+__device__ __forceinline__ void hot_load_market(const HotParams& P, HotLoads& Q)
+{
+    const float* pA = P.pool32;
+#pragma unroll
+    for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<float>(pA + q, Q.hb4);     // uniform (base + q) + one lane offset
+    if (MOD) {
+        const float* pB = P.pool32 + P.off_featB;
+#pragma unroll
+        for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<float>(pB + q, Q.hb4);
+    } else {
+        const float* pG = P.pool32 + P.off_gasn;
+        const float* pU = P.pool32 + P.off_euan;
+        Q.fb[0] = ld_off<float>(pG, Q.db4); Q.fb[1] = ld_off<float>(pG + 1, Q.db4);
+        Q.fb[2] = ld_off<float>(pU, Q.db4); Q.fb[3] = ld_off<float>(pU + 1, Q.db4);
+    }
+    Q.sc = ld_off<float2>(P.pool32 + P.off_sc, Q.kk8);
+}
+
+// k1 = step count after this step: UNIFORM (the hot kernels only run on a synchronised batch), so the clock arithmetic of
+// :442-445 is scalar; only the episode offset act_ep_d differs between envs
+template <bool MOD, int NOISE, bool MARKET = true>
 __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
-                                          HotRegs& R, int act, int e, HotLoads& Q)
+                                          HotRegs& R, int act, int e, int k1, HotLoads& Q)
 {
     const unsigned mset = (R.flags >> 15) & 3;
-    const int k1 = R.k + 1;
     const int secs = k1 * P.sim_step;
-    int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
+    const int hs = secs / 3600, ds = secs / 86400;
+    int H = R.act_d * 24 + hs, D = R.act_d + ds;
     const bool oob = (H + 13 > P.n_hours) | (D + 2 > P.n_days) | (H < 0) | (D < 0);
     if (__ballot(oob)) {
         if (oob) { atomicOr(P.err, 2); H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
     }
     const unsigned hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u, db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
-    const float* pA = P.pool32;
-#pragma unroll
-    for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<float>(pA + q, hb4);       // uniform (base + q) + one lane offset: merges to dwordx4
-    if (MOD) {
-        const float* pB = P.pool32 + P.off_featB;
-#pragma unroll
-        for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<float>(pB + q, hb4);
-    } else {
-        const float* pG = P.pool32 + P.off_gasn;
-        const float* pU = P.pool32 + P.off_euan;
-        Q.fb[0] = ld_off<float>(pG, db4); Q.fb[1] = ld_off<float>(pG + 1, db4);
-        Q.fb[2] = ld_off<float>(pU, db4); Q.fb[3] = ld_off<float>(pU + 1, db4);
-    }
-    Q.sc = ld_off<float2>(P.pool32 + P.off_sc, (unsigned)(k1 <= P.eps_sim_steps ? k1 : P.eps_sim_steps) * 8u);
+    Q.hb4 = hb4; Q.db4 = db4; Q.kk8 = (unsigned)min(k1, P.eps_sim_steps) * 8u;
+    if (MARKET) hot_load_market<MOD>(P, Q);
     Q.el = ld_off<double>(P.pool64, hb4 * 2u);
     Q.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
     Q.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
@@ -971,7 +921,6 @@ __device__ __forceinline__ float hot_back(const HotParams& P, HotRegs& R, const 
     R.cum += rew;
     rew -= Q.changed ? setc.y : 0.0;                                         // :332 (setc.y = r_0 * penalty, 0 by default)
     if (P.track_changes) { if (Q.changed && live) P.st_c[e].nchg += 1; }     // lanes past N shadow env N-1: no side effects
-    R.k += 1;
     return (float)rew;
 }
 
@@ -1009,7 +958,7 @@ template <int ACTK>
 __device__ __forceinline__ int hot_decode(const HotParams& P, int raw_i, float raw_f, unsigned flags)
 {
     const int prev = (flags >> 12) & 7;
-    if (ACTK == PTG_ACT_F32) return decode_action(&raw_f, PTG_ACT_F32, 0, prev);
+    if (ACTK == PTG_ACT_F32) return decode_continuous(raw_f, prev);
     const bool bad = (raw_i < -5) | (raw_i > 4);
     if (__ballot(bad)) { if (bad) atomicOr(P.err, 1); }
     return bad ? prev : (raw_i < 0 ? raw_i + 5 : raw_i);
@@ -1026,7 +975,7 @@ __device__ __forceinline__ void hot_fetch(const void* actions, size_t g, int& ri
 // one vector step, no env terminates (host-guaranteed); lanes past N shadow env N-1 and store nothing
 template <bool FM, bool MOD, int NOISE, int ACTK>
 __global__ void __launch_bounds__(256)
-k_step_hot(const HotParams P, const void* __restrict__ actions, float* __restrict__ obs, float* __restrict__ rew,
+k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* __restrict__ obs, float* __restrict__ rew,
            uint8_t* __restrict__ done)
 {
     __shared__ HotLds L;
@@ -1043,13 +992,13 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, float* __restric
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const int act = hot_decode<ACTK>(P, ri, rf, R.flags);
     HotLoads Q;
-    hot_front<MOD, NOISE>(P, L, nullptr, false, R, act, e, Q);
+    hot_front<MOD, NOISE>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
     const float r = hot_back(P, R, Q, setc, e, live);
     if (live) {
         hot_store_obs<FM, MOD>(HotRow<FM>(obs, P, e), Q, R.flags & 7);
         st_off<float>(rew, (unsigned)e * 4u, r);
         st_off<uint8_t>(done, (unsigned)e, 0);
-        StA na; na.i = R.i; na.j = R.j; na.k = R.k; na.flags = R.flags;
+        StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
         StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
         P.st_a[e] = na; P.st_b[e] = nb;
     }
@@ -1059,7 +1008,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, float* __restric
 // steps ahead, loads of step t+1 issued before the stores of step t
 template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT>
 __global__ void __launch_bounds__(512)
-k_rollout_hot(const HotParams P, const void* __restrict__ actions, int T, float* __restrict__ obs, float* __restrict__ rew,
+k_rollout_hot(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
               uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -1086,7 +1035,7 @@ k_rollout_hot(const HotParams P, const void* __restrict__ actions, int T, float*
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
     HotLoads Q;
-    hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, Q);      // prologue: front half of step 0
+    hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, k0 + 1, Q);   // prologue: front half of step 0
     char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;
     for (int t = 0; t < T; t++) {
         const float r = hot_back(P, R, Q, setc, e, live);   // needs the record of step t
@@ -1095,7 +1044,7 @@ k_rollout_hot(const HotParams P, const void* __restrict__ actions, int T, float*
         if (t + 1 < T) {                                    // front half of step t+1 BEFORE the stores of step t
             const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
             if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
-            hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, Qn);
+            hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, k0 + t + 2, Qn);
         }
         if (live) {
             hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
@@ -1106,7 +1055,121 @@ k_rollout_hot(const HotParams P, const void* __restrict__ actions, int T, float*
         Q = Qn;
     }
     if (live) {
-        StA na; na.i = R.i; na.j = R.j; na.k = R.k; na.flags = R.flags;
+        StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
+        StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
+        P.st_a[e] = na; P.st_b[e] = nb;
+    }
+}
+
+
+// Producer / consumer form of the fused rollout.  Half of every workgroup's waves (producers) run the state machine, the
+// record gather and the reward for one env per lane and hand each step's per-env results {hour offset, step offset,
+// METH_STATUS, six plant features, reward} to the other half (consumers) through a double-buffered LDS slot; the consumers
+// fetch the 26 market + 2 clock features and issue the 37 stores of the step.  With two waves per SIMD the stores of step
+// t-1 (HBM-rate) overlap the dependent instruction chain of step t instead of queueing behind it.  One barrier per step.
+struct PcSlot {                  // structure of arrays: consecutive lanes hit consecutive banks
+    unsigned hb4[256], db4[256], kk8[256];
+    float s[256], feat[6][256], rew[256];
+};
+
+template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT>
+__global__ void __launch_bounds__(512)
+k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
+             uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    HotLds& L = *(HotLds*)s_dyn;
+    PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
+    unsigned short* s_lut = (unsigned short*)((unsigned char*)slot + 2 * sizeof(PcSlot));
+    const int NP = blockDim.x / 2;                          // envs per workgroup (<= 256)
+    const bool producer = (int)threadIdx.x < NP;
+    const int lx = producer ? threadIdx.x : threadIdx.x - NP;
+    const int e_raw = blockIdx.x * NP + lx;
+    const bool live = e_raw < P.N;
+    const int e = live ? e_raw : P.N - 1;
+    HotRegs R;
+    R.i = R.j = R.k = 0; R.flags = 1u; R.cum = 0.0; R.act_d = 0; R.nctr = 0;
+    int ri = 0, ni = 0; float rf = 0.f, nf = 0.f;
+    if (producer) {
+        const StA a = P.st_a[e]; const StB b = P.st_b[e];
+        R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
+        hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
+        if (T > 1) hot_fetch<ACTK>(actions, (size_t)P.N + e, ni, nf);
+    }
+    hot_stage_lds(P, L);
+    if (LDSLUT) {
+        const int words = (N_DEST * P.nT + 1) / 2;
+        const unsigned* src = (const unsigned*)lut16;
+        unsigned* dst = (unsigned*)s_lut;
+        for (int q = threadIdx.x; q < words; q += blockDim.x) dst[q] = src[q];
+    }
+    __syncthreads();
+    const unsigned short* lut = LDSLUT ? s_lut : nullptr;
+    HotLoads Q;
+    double2 setc = make_double2(0.0, 0.0);
+    if (producer) {
+        setc = P.setc[(R.flags >> 15) & 3];
+        hot_front<MOD, NOISE, false>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, k0 + 1, Q);   // front half of step 0
+    }
+    const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
+    char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of step it-1
+    const bool stamp = (P.dbg & 16) != 0;
+    long long tA = 0, tB = 0, tC = 0, t0 = 0, t1 = 0, t2 = 0;
+    for (int it = 0; it <= T; it++) {
+        if (stamp) t0 = __builtin_amdgcn_s_memtime();
+        if (producer) {
+            if (it < T) {
+                PcSlot& S = slot[it & 1];
+                const float r = hot_back(P, R, Q, setc, e, live);
+                if (stamp) { t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; }
+                S.hb4[lx] = Q.hb4; S.db4[lx] = Q.db4; S.kk8[lx] = Q.kk8;
+                S.s[lx] = (float)(R.flags & 7);
+#pragma unroll
+                for (int q = 0; q < 6; q++) S.feat[q][lx] = Q.rec.feat[q];
+                S.rew[lx] = r;
+                if (it + 1 < T) {
+                    const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
+                    if (it + 2 < T) hot_fetch<ACTK>(actions, (size_t)(it + 2) * P.N + e, ni, nf);
+                    hot_front<MOD, NOISE, false>(P, L, lut, LDSLUT, R, act, e, k0 + it + 2, Q);
+                }
+            }
+        } else if (it >= 1) {
+            const PcSlot& S = slot[(it - 1) & 1];
+            HotLoads C;
+            C.hb4 = S.hb4[lx]; C.db4 = S.db4[lx]; C.kk8 = S.kk8[lx];
+            hot_load_market<MOD>(P, C);
+            if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; }
+            const float sv = S.s[lx];
+#pragma unroll
+            for (int q = 0; q < 6; q++) C.rec.feat[q] = S.feat[q][lx];
+            const float r = S.rew[lx];
+            if (live) {
+                const HotRow<FM> row((float*)obs_t, P, e);
+#pragma unroll
+                for (int q = 0; q < 13; q++) row.put(q, C.fa[q]);
+#pragma unroll
+                for (int q = 0; q < (MOD ? 13 : 4); q++) row.put(13 + q, C.fb[q]);
+                constexpr int o = MOD ? 26 : 17;
+                row.put(o + 0, sv);
+#pragma unroll
+                for (int q = 0; q < 6; q++) row.put(o + 1 + q, C.rec.feat[q]);
+                row.put(o + 7, C.sc.x);
+                row.put(o + 8, C.sc.y);
+                st_off<float>(rew_t, (unsigned)e * 4u, r);
+                st_off<uint8_t>(done_t, (unsigned)e, 0);
+            }
+            obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
+        }
+        if (stamp) { t2 = __builtin_amdgcn_s_memtime(); tB += t2 - t0; }
+        __syncthreads();
+        if (stamp) { tC += __builtin_amdgcn_s_memtime() - t2; }
+    }
+    if (stamp && blockIdx.x == 17 && (threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        P.dbg_out[w * 4 + 0] = tA; P.dbg_out[w * 4 + 1] = tB; P.dbg_out[w * 4 + 2] = tC; P.dbg_out[w * 4 + 3] = T;
+    }
+    if (producer && live) {
+        StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
         StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
         P.st_a[e] = na; P.st_b[e] = nb;
     }
@@ -1131,6 +1194,7 @@ struct ptg_env {
     unsigned off_featB = 0, off_gasn = 0, off_euan = 0, off_gas = 0, off_eua = 0, off_sc = 0;
     std::vector<float> pool32_host;
     int* d_ladder = nullptr;
+    long long* d_dbg = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
@@ -1363,6 +1427,7 @@ HotParams make_hot_params(const ptg_env* h)
     F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.noise_sigma = P.noise_sigma; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
     F.recf = P.recf; F.tape = P.tape; F.pool32 = h->d_pool32; F.pool64 = h->d_pool64; F.setc = P.setc; F.argidx = P.argidx;
     F.tabmeta = P.tabmeta; F.ladder = h->d_ladder; F.st_a = P.st_a; F.st_b = P.st_b; F.st_c = P.st_c; F.err = P.err;
+    F.dbg_out = h->d_dbg;
     return F;
 }
 
@@ -1380,14 +1445,39 @@ void launch_step_hot(const ptg_env* h, hipStream_t st, const void* actions, int 
 {
     const HotParams hp = make_hot_params(h);
     const dim3 grid(grid_for(h->n, 256)), block(256);
-    if (kind == PTG_ACT_F32) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_F32>), grid, block, 0, st, hp, actions, obs, rew, done);
-    else if (kind == PTG_ACT_I64) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I64>), grid, block, 0, st, hp, actions, obs, rew, done);
-    else hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, obs, rew, done);
+    if (kind == PTG_ACT_F32) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_F32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+    else if (kind == PTG_ACT_I64) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I64>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+    else hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+}
+
+template <bool FM, bool MOD, int NOISE>
+void launch_rollout_pc(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
+{
+    const HotParams hp = make_hot_params(h);
+    int bs = 128;                                           // half producers, half consumers; >= 256 workgroups when possible
+    while (bs < 512 && (long long)grid_for(h->n, bs) >= 256) bs *= 2;     // bs/2 envs per workgroup
+    if (getenv("PTG_BLOCK")) bs = atoi(getenv("PTG_BLOCK"));
+    const dim3 grid(grid_for(h->n, bs / 2)), block(bs);
+    const size_t l_bytes = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);
+    const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
+    const bool ll = h->d_lut16 && l_bytes + lut_bytes <= 160000 && !getenv("PTG_NO_LDS_LUT");
+    const size_t sh = l_bytes + (ll ? lut_bytes : 0);
+#define PTG_PC(ACTK, LL)                                                                                              \
+    do {                                                                                                              \
+        auto kfn = k_rollout_pc<FM, MOD, NOISE, ACTK, LL>;                                                            \
+        if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16);                    \
+    } while (0)
+    if (kind == PTG_ACT_F32) { if (ll) PTG_PC(PTG_ACT_F32, true); else PTG_PC(PTG_ACT_F32, false); }
+    else if (kind == PTG_ACT_I64) { if (ll) PTG_PC(PTG_ACT_I64, true); else PTG_PC(PTG_ACT_I64, false); }
+    else { if (ll) PTG_PC(PTG_ACT_I32, true); else PTG_PC(PTG_ACT_I32, false); }
+#undef PTG_PC
 }
 
 template <bool FM, bool MOD, int NOISE>
 void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
 {
+    if (getenv("PTG_USE_PC")) { launch_rollout_pc<FM, MOD, NOISE>(h, st, actions, kind, T, obs, rew, done); return; }   // experimental, same speed
     const HotParams hp = make_hot_params(h);
     int bs = 64;                                            // one lane per env; >= 256 workgroups when the batch allows, <= 512 threads
     while (bs < 512 && (long long)grid_for(h->n, bs * 2) >= 256) bs *= 2;
@@ -1397,7 +1487,7 @@ void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, i
     const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
     const bool ll = h->d_lut16 && l_bytes + lut_bytes <= 64000 && !getenv("PTG_NO_LDS_LUT");
     const size_t sh = l_bytes + (ll ? lut_bytes : 0);
-#define PTG_RH(ACTK, LL) hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL>), grid, block, sh, st, hp, actions, T, obs, rew, done, h->d_lut16)
+#define PTG_RH(ACTK, LL) hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL>), grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16)
     if (kind == PTG_ACT_F32) { if (ll) PTG_RH(PTG_ACT_F32, true); else PTG_RH(PTG_ACT_F32, false); }
     else if (kind == PTG_ACT_I64) { if (ll) PTG_RH(PTG_ACT_I64, true); else PTG_RH(PTG_ACT_I64, false); }
     else { if (ll) PTG_RH(PTG_ACT_I32, true); else PTG_RH(PTG_ACT_I32, false); }
@@ -1564,6 +1654,8 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
                                 P.t45_p_f_p, P.t5_p_f_p, P.t1_f_p_f, P.t2_f_p_f, P.t23_f_p_f, P.t3_f_p_f, P.t34_f_p_f, P.t4_f_p_f, P.t45_f_p_f,
                                 P.t5_f_p_f, P.i_full, P.j_full};
         if ((rc = dev_upload(h, &h->d_ladder, lad, LAD_N))) return fail(rc);
+        if ((rc = dev_alloc(h, &h->d_dbg, 64))) return fail(rc);
+        (void)hipMemset(h->d_dbg, 0, 64 * sizeof(long long));
     }
     hipLaunchKernelGGL(k_init_state, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, P, 0, 0);
     if ((rc = launch_check(h, "k_init_state"))) return fail(rc);
@@ -1733,30 +1825,19 @@ static int launch_step_generic(ptg_env* h, hipStream_t st, const void* actions_d
     return launch_check(h, "k_step");
 }
 
+// generic rollout = T generic step launches (measured faster than a fused generic kernel, whose register pressure spills):
+// float64 outputs, unusual price_ahead, de-synchronised batches, and the one terminating step per episode take this route
 static int launch_rollout_generic(ptg_env* h, hipStream_t st, const void* actions_dev, int action_kind, int n_steps, void* obs_dev,
                                   void* rew_dev, uint8_t* done_dev)
 {
-    // block size: one lane per env, >= 256 workgroups when the batch allows it (one per CU), up to 1024 threads (4 waves/SIMD)
-    int bs = 64;
-    while (bs < 1024 && (long long)grid_for(h->n, bs * 2) >= 256) bs *= 2;
-    const dim3 rgrid(grid_for(h->n, bs)), rblock(bs);
-    const size_t tm_bytes = 16 * ((NT * sizeof(int2) + 15) / 16);
-    const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
-    const bool ldslut = h->d_lut16 && tm_bytes + lut_bytes <= 64000;
-    const size_t shmem = tm_bytes + (ldslut ? lut_bytes : 0);
-#define PTG_LAUNCH_ROLL__(OUT, FAST, FM, PAC, LL)                                                                 \
-    hipLaunchKernelGGL((k_rollout<OUT, FAST, FM, PAC, LL>), rgrid, rblock, shmem, st, h->P, actions_dev, action_kind, n_steps, \
-                       (OUT*)obs_dev, (OUT*)rew_dev, done_dev, h->d_lut16)
-#define PTG_LAUNCH_ROLL_(OUT, FAST, FM, PAC)                                                                      \
-    do { if (ldslut) PTG_LAUNCH_ROLL__(OUT, FAST, FM, PAC, true); else PTG_LAUNCH_ROLL__(OUT, FAST, FM, PAC, false); } while (0)
-#define PTG_LAUNCH_ROLL(OUT, FAST, FM)                                                                           \
-    do { if (h->cfg.price_ahead == 13) PTG_LAUNCH_ROLL_(OUT, FAST, FM, 13); else PTG_LAUNCH_ROLL_(OUT, FAST, FM, 0); } while (0)
-    if (h->cfg.out_dtype == PTG_OUT_F64) { if (h->fm) PTG_LAUNCH_ROLL(double, false, true); else PTG_LAUNCH_ROLL(double, false, false); }
-    else { if (h->fm) PTG_LAUNCH_ROLL(float, true, true); else PTG_LAUNCH_ROLL(float, true, false); }
-#undef PTG_LAUNCH_ROLL
-#undef PTG_LAUNCH_ROLL_
-#undef PTG_LAUNCH_ROLL__
-    return launch_check(h, "k_rollout");
+    const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    for (int t = 0; t < n_steps; t++) {
+        const int rc = launch_step_generic(h, st, (const char*)actions_dev + (size_t)t * h->n * asz, action_kind,
+                                           (char*)obs_dev + (size_t)t * h->n * h->F * osz, (char*)rew_dev + (size_t)t * h->n * osz,
+                                           done_dev + (size_t)t * h->n, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev, uint8_t* done_dev,
@@ -1960,6 +2041,15 @@ int ptg_debug_get_index_lut(ptg_env* h, double* T_values_host, int32_t* lut_host
     *n_T = (int)h->Tvals.size();
     if (T_values_host) memcpy(T_values_host, h->Tvals.data(), sizeof(double) * h->Tvals.size());
     if (lut_host) HIP_TRY(h, hipMemcpy(lut_host, h->P.argidx, sizeof(int) * N_DEST * h->Tvals.size(), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ptg_debug_read_counters(ptg_env* h, long long* out64_host)
+{
+    if (!h || !out64_host) return PTG_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(out64_host, h->d_dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
