@@ -73,9 +73,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--path", choices=["step", "rollout"], default="step", help="timed path; the other one is measured too (--no-also to skip)")
+    ap.add_argument("--path", choices=["step", "rollout"], default="rollout",
+                    help="timed path: ptg_rollout (K steps fused in one launch) or ptg_step (one launch per step); the other one is "
+                         "measured too and reported under \"also\" (--no-also to skip)")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step path: replay the K launches as one hipGraph, or launch eagerly")
     ap.add_argument("--no-also", dest="also", action="store_false")
     ap.add_argument("--scenario", type=int, default=1)
@@ -103,11 +105,17 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the env step has no CPU path")
+    backend = os.environ.get("PTG_BENCH_BACKEND", "nccl")       # "gloo": rehearse the N > 1 path with several ranks on one GPU
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     K, W, n = args.steps, args.warmup, args.envs
     n_total = n * world
@@ -166,7 +174,7 @@ def main():
             run(W, K)
         ev1.record()
         r, l, _ = eng.finished_episodes()          # synchronises; episodic-return reduction (one all-gather, off the step path)
-        r_all, l_all = ptg_dist.all_gather_finished(r, l, device=device)
+        r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -174,7 +182,7 @@ def main():
         eng.sync()
         dev_ms = ev0.elapsed_time(ev1)
         if world > 1:
-            tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+            tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=coll_device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed, dev_ms = float(tmax[0]), float(tmax[1])
         eng.close()
@@ -197,13 +205,19 @@ def main():
     if rank == 0:
         out_bytes = 4 if args.out_dtype == "float32" else 8
         roof = roofline(args.path, dev_ms, out_bytes)
+        tj = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))          # measured with rocprofv3 PMC passes (profiles/*_summary.md), per launch like `achieved`
-                roof["traffic"] = tj.get("step_bytes_per_launch") if args.path == "step" else tj.get("rollout_bytes_per_step", 0) * K
+        if os.path.exists(tpath) and n == 65536 and args.out_dtype == "float32" and args.obs_layout == "feature":
+            try:                                      # measured with rocprofv3 PMC passes on this workload (profiles/*_summary.md)
+                tj = json.load(open(tpath))
             except Exception:
-                pass
+                tj = {}
+
+        def traffic(path):                            # HBM bytes per launch, like `achieved`
+            if path == "step":
+                return tj.get("step_bytes_per_launch")
+            return tj["rollout_bytes_per_step"] * K if "rollout_bytes_per_step" in tj else None
+        roof["traffic"] = traffic(args.path)
         path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
                      "rollout": "ptg_rollout, K steps fused in one launch"}
         line = {
@@ -220,7 +234,7 @@ def main():
         }
         if o_elapsed is not None:
             line["also"] = {"path": path_name[other], "value": n_total * K / o_elapsed, "unit": "env-steps/s",
-                            "ms_per_step": o_elapsed * 1e3 / K, "roofline": roofline(other, o_dev_ms, out_bytes)}
+                            "ms_per_step": o_elapsed * 1e3 / K, "roofline": dict(roofline(other, o_dev_ms, out_bytes), traffic=traffic(other))}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))

@@ -928,7 +928,13 @@ template <bool FM>
 struct HotRow {                  // observation row addressing: uniform base + 32-bit lane byte offset (feature q adds q * qbytes)
     char* base; unsigned boff; unsigned qbytes;
     __device__ __forceinline__ HotRow(float* b, const HotParams& P, int e)
-        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u) {}
+        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u)
+    {
+        if (FM && (P.dbg & 32)) {     // experiment: wave-blocked feature-major [N/64][F][64]
+            boff = (((unsigned)e >> 6) * (unsigned)P.F * 64u + ((unsigned)e & 63u)) * 4u;
+            qbytes = 256u;
+        }
+    }
     __device__ __forceinline__ void put(int q, float v) const { st_off<float>(base, boff + (unsigned)q * qbytes, v); }
 };
 
@@ -1006,8 +1012,8 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
 
 // T fused steps, no env terminates inside (host-guaranteed): state in registers, small tables in LDS, actions fetched two
 // steps ahead, loads of step t+1 issued before the stores of step t
-template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT>
-__global__ void __launch_bounds__(512)
+template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT, bool PIPE>
+__global__ void __launch_bounds__(512, PIPE ? 1 : 3)      // plain order: <= 168 VGPRs, 3 waves per SIMD (4 would spill)
 k_rollout_hot(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
               uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
 {
@@ -1040,19 +1046,32 @@ k_rollout_hot(const HotParams P, const void* __restrict__ actions, int k0, int T
     for (int t = 0; t < T; t++) {
         const float r = hot_back(P, R, Q, setc, e, live);   // needs the record of step t
         const int s_out = R.flags & 7;
-        HotLoads Qn;
-        if (t + 1 < T) {                                    // front half of step t+1 BEFORE the stores of step t
-            const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
-            if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
-            hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, k0 + t + 2, Qn);
-        }
-        if (live) {
-            hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
-            st_off<float>(rew_t, (unsigned)e * 4u, r);
-            st_off<uint8_t>(done_t, (unsigned)e, 0);
+        if (PIPE) {                                         // one wave per SIMD: order the stream by hand
+            HotLoads Qn;
+            if (t + 1 < T) {                                // front half of step t+1 BEFORE the stores of step t
+                const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
+                if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
+                hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, k0 + t + 2, Qn);
+            }
+            if (live) {
+                hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
+                st_off<float>(rew_t, (unsigned)e * 4u, r);
+                st_off<uint8_t>(done_t, (unsigned)e, 0);
+            }
+            Q = Qn;
+        } else {                                            // large batches: several waves per SIMD hide latency; fewer registers
+            if (live) {
+                hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
+                st_off<float>(rew_t, (unsigned)e * 4u, r);
+                st_off<uint8_t>(done_t, (unsigned)e, 0);
+            }
+            if (t + 1 < T) {
+                const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
+                if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
+                hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, k0 + t + 2, Q);
+            }
         }
         obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
-        Q = Qn;
     }
     if (live) {
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
@@ -1487,7 +1506,10 @@ void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, i
     const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
     const bool ll = h->d_lut16 && l_bytes + lut_bytes <= 64000 && !getenv("PTG_NO_LDS_LUT");
     const size_t sh = l_bytes + (ll ? lut_bytes : 0);
-#define PTG_RH(ACTK, LL) hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL>), grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16)
+    // one wave per SIMD (N <= 65 536 per GPU): software-pipelined stream; larger batches: plain order, fewer registers
+    const bool pipe = getenv("PTG_PIPE") ? atoi(getenv("PTG_PIPE")) != 0 : (h->n <= 65536);
+#define PTG_RH(ACTK, LL) do { if (pipe) hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL, true>), grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16); \
+                              else hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL, false>), grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16); } while (0)
     if (kind == PTG_ACT_F32) { if (ll) PTG_RH(PTG_ACT_F32, true); else PTG_RH(PTG_ACT_F32, false); }
     else if (kind == PTG_ACT_I64) { if (ll) PTG_RH(PTG_ACT_I64, true); else PTG_RH(PTG_ACT_I64, false); }
     else { if (ll) PTG_RH(PTG_ACT_I32, true); else PTG_RH(PTG_ACT_I32, false); }

@@ -44,7 +44,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 lines = [f"# rocprofv3 summary, {tag}", "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline` (1x MI355X, N = 65536 envs,",
+         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (defaults: 200 warm-up + 200 timed steps of both",
+         "paths: every k_rollout_hot dispatch is one 200-step launch, every k_step_hot dispatch one vector step; 1x MI355X, N = 65536 envs,",
          "BS1/OP1, float32 feature-major obs, in-kernel RNG).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of",
          "`bench.py --steps 50 --warmup 5 --launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads);",
          "counter unit KiB.", "",
