@@ -176,12 +176,14 @@ def _oracle_for(spec, n, tape):
     return ora
 
 
-def test_device_rng_tape_vs_oracle_and_inline_mode():
-    """N = 4096, uniform-random actions (43 % state changes): the HIP path with a device-generated noise tape equals the
-    oracle fed the same tape, and the in-kernel RNG mode equals the tape mode bit for bit."""
+@pytest.mark.parametrize("scenario,operation", [(1, "OP1"), (2, "OP2"), (3, "OP2")])
+def test_device_rng_tape_vs_oracle_and_inline_mode(scenario, operation):
+    """N = 4096 (BASELINE.json configs[1] size), uniform-random actions (43 % state changes), every business scenario: the HIP
+    path with a device-generated noise tape equals the oracle fed the same tape, and the in-kernel RNG mode equals the tape
+    mode bit for bit."""
     n, K, L = 4096, 120, 128
-    spec, e_tape = _synthetic_engine(n)
-    _, e_rng = _synthetic_engine(n)
+    spec, e_tape = _synthetic_engine(n, scenario, operation)
+    _, e_rng = _synthetic_engine(n, scenario, operation)
     e_tape.fill_noise_tape(seed=77, per_env_len=L)
     e_rng.set_noise_rng(seed=77)
     tape = e_tape.get_noise_tape(L)
@@ -293,3 +295,31 @@ def test_sharded_engines_equal_one_batch():
     ms = full.get_state("market_set")
     assert len({round(float(np.mean(rF[np.argsort(iF)][ms == q])), 3) for q in range(3)}) == 3
     full.close(); s0.close(); s1.close()
+
+
+def test_full_size_properties_n262144_bs3():
+    """BASELINE.json configs[3]: N = 262 144, BS3/OP2 (CHP / EEG reward path).  Fused rollout == per-step launches (bit-equal),
+    float32 hot path == float64 reference-order path within one float32 rounding, CHP revenue present."""
+    n, K = 262144, 10
+    spec, a64 = _synthetic_engine(n, 3, "OP2", out_dtype="float64", layout="feature")
+    _, a32 = _synthetic_engine(n, 3, "OP2", out_dtype="float32", layout="feature")
+    _, b32 = _synthetic_engine(n, 3, "OP2", out_dtype="float32", layout="feature")
+    for e in (a64, a32, b32):
+        e.set_noise_rng(7)
+        e.reset()
+    rng = np.random.default_rng(2)
+    acts = rng.integers(0, 5, (K, n)).astype(np.int32)
+    acts[:4] = 2                                          # everybody starts up first
+    ro, rr, rd = b32.rollout(acts)
+    b32.sync()
+    for t in range(K):
+        o64, r64, _ = a64.step(acts[t])
+        o32, r32, _ = a32.step(acts[t])
+        a64.sync(); a32.sync()
+        assert np.array_equal(ro[t].cpu().numpy(), o32.cpu().numpy()) and np.array_equal(rr[t].cpu().numpy(), r32.cpu().numpy())
+        np.testing.assert_allclose(o32.cpu().numpy(), o64.cpu().numpy(), rtol=RTOL32, atol=ATOL32)
+        np.testing.assert_allclose(r32.cpu().numpy(), r64.cpu().numpy(), rtol=RTOL32, atol=1e-6)
+    for f in INT_FIELDS:
+        assert np.array_equal(a32.get_state(f), a64.get_state(f)) and np.array_equal(b32.get_state(f), a32.get_state(f)), f
+    assert int(rd.sum()) == 0
+    a64.close(); a32.close(); b32.close()
