@@ -180,7 +180,6 @@ int ptg_finished_episodes(ptg_env* env, double* returns_host, int32_t* lengths_h
 /* diagnostics for tests: the device-built lookup products */
 int ptg_debug_get_index_lut(ptg_env* env, double* T_values_host, int32_t* lut_host /*[6][nT]*/, int* n_T);
 int ptg_debug_window_record(ptg_env* env, int table_id, int start_row, double* out7_host /*T_last, 5 means, key*/);
-int ptg_debug_read_counters(ptg_env* env, long long* out64_host);   /* per-phase cycle sums written by PTG_DEBUG_FLAGS=16 builds */
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,6 @@ struct DevParams {
     unsigned long long noise_seed;
     long long env_offset;                  // global index of env 0 of this shard (keys the RNG streams)
     double noise_sigma;
-    int dbg;                               // PTG_DEBUG_FLAGS (timing experiments only; 0 in production)
     int key_cold_max, key_hot_min, key_standby_max, key_init, i_reset, nT, tape_len;
     int n_hours, n_days, hstride, dstride;
     int t1_start_p_f, t2_start_f_p, t_p_f, t_f_p, t1_p_f_p, t2_p_f_p, t3_p_f_p, t34_p_f_p, t4_p_f_p, t45_p_f_p,
@@ -487,8 +486,7 @@ __device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta
     PriceFeatures<OUT, FAST, FM, PAC> pf;
     if (row) pf.load(P, mset, H, D);
     bool changed;
-    int ridx = step_ints(P, tabmeta, lut, R, act, e, changed);
-    if (P.dbg & 2) ridx = ridx & 1023;
+    const int ridx = step_ints(P, tabmeta, lut, R, act, e, changed);
     const int s = R.a.flags & 7;
     double rew;
     if (FAST) {
@@ -733,7 +731,7 @@ enum { LAD_T1_START_P_F = 0, LAD_T2_START_F_P, LAD_T_P_F, LAD_T_F_P, LAD_T1_P_F_
 
 struct HotParams {
     int N, S, sim_step, eps_sim_steps, F, nT, tape_len, track_changes;
-    int key_cold_max, key_hot_min, key_standby_max, n_hours, n_days, hstride, dstride, dbg;
+    int key_cold_max, key_hot_min, key_standby_max, n_hours, n_days, hstride, dstride;
     unsigned off_featB, off_gasn, off_euan, off_sc;   // element offsets into pool32 (featA at 0; sin/cos pairs at off_sc)
     unsigned off_gas, off_eua;                        // element offsets into pool64 (el at 0)
     unsigned long long noise_seed;
@@ -749,7 +747,6 @@ struct HotParams {
     const int* ladder;                                // [LAD_N]
     StA* st_a; StB* st_b; StC* st_c;
     int* err;
-    long long* dbg_out;                               // timing experiments (PTG_DEBUG_FLAGS & 16): per-phase cycle sums of block 0
 };
 
 struct HotLds {                  // per-workgroup LDS image
@@ -928,13 +925,7 @@ template <bool FM>
 struct HotRow {                  // observation row addressing: uniform base + 32-bit lane byte offset (feature q adds q * qbytes)
     char* base; unsigned boff; unsigned qbytes;
     __device__ __forceinline__ HotRow(float* b, const HotParams& P, int e)
-        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u)
-    {
-        if (FM && (P.dbg & 32)) {     // experiment: wave-blocked feature-major [N/64][F][64]
-            boff = (((unsigned)e >> 6) * (unsigned)P.F * 64u + ((unsigned)e & 63u)) * 4u;
-            qbytes = 256u;
-        }
-    }
+        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u) {}
     __device__ __forceinline__ void put(int q, float v) const { st_off<float>(base, boff + (unsigned)q * qbytes, v); }
 };
 
@@ -1082,12 +1073,13 @@ k_rollout_hot(const HotParams P, const void* __restrict__ actions, int k0, int T
 
 
 // Producer / consumer form of the fused rollout.  Half of every workgroup's waves (producers) run the state machine, the
-// record gather and the reward for one env per lane and hand each step's per-env results {hour offset, step offset,
-// METH_STATUS, six plant features, reward} to the other half (consumers) through a double-buffered LDS slot; the consumers
-// fetch the 26 market + 2 clock features and issue the 37 stores of the step.  With two waves per SIMD the stores of step
-// t-1 (HBM-rate) overlap the dependent instruction chain of step t instead of queueing behind it.  One barrier per step.
+// record gather and the reward for one env per lane and hand each step's per-env results {METH_STATUS, six plant features,
+// reward} to the other half (consumers) through a double-buffered LDS slot.  The consumers own everything that does not
+// depend on the state machine: the 26 market features (a function of the hour only -- reloaded when the hour changes, i.e.
+// every 3600 / sim_step steps, one step ahead of use), the two clock features (scalar loads: the step count is uniform),
+// and ALL stores of the step.  Two waves per SIMD: the store stream of step t-1 overlaps the dependent instruction chain
+// of step t.  One barrier per step.
 struct PcSlot {                  // structure of arrays: consecutive lanes hit consecutive banks
-    unsigned hb4[256], db4[256], kk8[256];
     float s[256], feat[6][256], rew[256];
 };
 
@@ -1106,12 +1098,11 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     const int e_raw = blockIdx.x * NP + lx;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
+    const StA a = P.st_a[e]; const StB b = P.st_b[e];
     HotRegs R;
-    R.i = R.j = R.k = 0; R.flags = 1u; R.cum = 0.0; R.act_d = 0; R.nctr = 0;
+    R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
     int ri = 0, ni = 0; float rf = 0.f, nf = 0.f;
     if (producer) {
-        const StA a = P.st_a[e]; const StB b = P.st_b[e];
-        R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
         hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
         if (T > 1) hot_fetch<ACTK>(actions, (size_t)P.N + e, ni, nf);
     }
@@ -1124,24 +1115,47 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     }
     __syncthreads();
     const unsigned short* lut = LDSLUT ? s_lut : nullptr;
-    HotLoads Q;
+    const unsigned mset = (R.flags >> 15) & 3;
+    HotLoads Q;                                             // producer: loads of the step in flight; consumer: current market features
+    HotLoads Qn;                                            // consumer: market features of the next hour
     double2 setc = make_double2(0.0, 0.0);
+    // series offsets of step count k1 for this env (:442-447); uniform except for the episode offset
+    auto offsets = [&](int k1, unsigned& hb4, unsigned& db4) {
+        const int secs = k1 * P.sim_step;
+        int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
+        H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2));      // range errors are flagged by the producers
+        hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u;
+        db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
+    };
+    int hour_cur = 0;
     if (producer) {
-        setc = P.setc[(R.flags >> 15) & 3];
+        setc = P.setc[mset];
         hot_front<MOD, NOISE, false>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, k0 + 1, Q);   // front half of step 0
+    } else {
+        offsets(k0 + 1, Q.hb4, Q.db4);
+        Q.kk8 = 0;
+        hour_cur = ((k0 + 1) * P.sim_step) / 3600;
+        const float* pA = P.pool32;
+#pragma unroll
+        for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<float>(pA + q, Q.hb4);
+        if (MOD) {
+            const float* pB = P.pool32 + P.off_featB;
+#pragma unroll
+            for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<float>(pB + q, Q.hb4);
+        } else {
+            const float* pG = P.pool32 + P.off_gasn;
+            const float* pU = P.pool32 + P.off_euan;
+            Q.fb[0] = ld_off<float>(pG, Q.db4); Q.fb[1] = ld_off<float>(pG + 1, Q.db4);
+            Q.fb[2] = ld_off<float>(pU, Q.db4); Q.fb[3] = ld_off<float>(pU + 1, Q.db4);
+        }
     }
     const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
     char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of step it-1
-    const bool stamp = (P.dbg & 16) != 0;
-    long long tA = 0, tB = 0, tC = 0, t0 = 0, t1 = 0, t2 = 0;
     for (int it = 0; it <= T; it++) {
-        if (stamp) t0 = __builtin_amdgcn_s_memtime();
         if (producer) {
             if (it < T) {
                 PcSlot& S = slot[it & 1];
                 const float r = hot_back(P, R, Q, setc, e, live);
-                if (stamp) { t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; }
-                S.hb4[lx] = Q.hb4; S.db4[lx] = Q.db4; S.kk8[lx] = Q.kk8;
                 S.s[lx] = (float)(R.flags & 7);
 #pragma unroll
                 for (int q = 0; q < 6; q++) S.feat[q][lx] = Q.rec.feat[q];
@@ -1153,39 +1167,56 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
                 }
             }
         } else if (it >= 1) {
-            const PcSlot& S = slot[(it - 1) & 1];
-            HotLoads C;
-            C.hb4 = S.hb4[lx]; C.db4 = S.db4[lx]; C.kk8 = S.kk8[lx];
-            hot_load_market<MOD>(P, C);
-            if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; }
-            const float sv = S.s[lx];
+            // step t = it-1 has step count k1 = k0 + it; the NEXT step's hour decides whether new market features are fetched now
+            const int k1 = k0 + it;
+            const int hour_next = ((k1 + 1) * P.sim_step) / 3600;
+            const bool reload = (hour_next != hour_cur) && (it < T);
+            if (reload) {                                   // uniform branch; loads issued BEFORE this step's stores
+                offsets(k1 + 1, Qn.hb4, Qn.db4);
+                const float* pA = P.pool32;
 #pragma unroll
-            for (int q = 0; q < 6; q++) C.rec.feat[q] = S.feat[q][lx];
+                for (int q = 0; q < 13; q++) Qn.fa[q] = ld_off<float>(pA + q, Qn.hb4);
+                if (MOD) {
+                    const float* pB = P.pool32 + P.off_featB;
+#pragma unroll
+                    for (int q = 0; q < 13; q++) Qn.fb[q] = ld_off<float>(pB + q, Qn.hb4);
+                } else {
+                    const float* pG = P.pool32 + P.off_gasn;
+                    const float* pU = P.pool32 + P.off_euan;
+                    Qn.fb[0] = ld_off<float>(pG, Qn.db4); Qn.fb[1] = ld_off<float>(pG + 1, Qn.db4);
+                    Qn.fb[2] = ld_off<float>(pU, Qn.db4); Qn.fb[3] = ld_off<float>(pU + 1, Qn.db4);
+                }
+            }
+            const float2 sc = ((const float2*)(P.pool32 + P.off_sc))[min(k1, P.eps_sim_steps)];     // uniform index: scalar load
+            const PcSlot& S = slot[(it - 1) & 1];
+            const float sv = S.s[lx];
+            float ft[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) ft[q] = S.feat[q][lx];
             const float r = S.rew[lx];
             if (live) {
                 const HotRow<FM> row((float*)obs_t, P, e);
 #pragma unroll
-                for (int q = 0; q < 13; q++) row.put(q, C.fa[q]);
+                for (int q = 0; q < 13; q++) row.put(q, Q.fa[q]);
 #pragma unroll
-                for (int q = 0; q < (MOD ? 13 : 4); q++) row.put(13 + q, C.fb[q]);
+                for (int q = 0; q < (MOD ? 13 : 4); q++) row.put(13 + q, Q.fb[q]);
                 constexpr int o = MOD ? 26 : 17;
                 row.put(o + 0, sv);
 #pragma unroll
-                for (int q = 0; q < 6; q++) row.put(o + 1 + q, C.rec.feat[q]);
-                row.put(o + 7, C.sc.x);
-                row.put(o + 8, C.sc.y);
+                for (int q = 0; q < 6; q++) row.put(o + 1 + q, ft[q]);
+                row.put(o + 7, sc.x);
+                row.put(o + 8, sc.y);
                 st_off<float>(rew_t, (unsigned)e * 4u, r);
                 st_off<uint8_t>(done_t, (unsigned)e, 0);
             }
             obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
+            if (reload) {
+#pragma unroll
+                for (int q = 0; q < 13; q++) { Q.fa[q] = Qn.fa[q]; Q.fb[q] = Qn.fb[q]; }
+                hour_cur = hour_next;
+            }
         }
-        if (stamp) { t2 = __builtin_amdgcn_s_memtime(); tB += t2 - t0; }
         __syncthreads();
-        if (stamp) { tC += __builtin_amdgcn_s_memtime() - t2; }
-    }
-    if (stamp && blockIdx.x == 17 && (threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        P.dbg_out[w * 4 + 0] = tA; P.dbg_out[w * 4 + 1] = tB; P.dbg_out[w * 4 + 2] = tC; P.dbg_out[w * 4 + 3] = T;
     }
     if (producer && live) {
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
@@ -1213,7 +1244,6 @@ struct ptg_env {
     unsigned off_featB = 0, off_gasn = 0, off_euan = 0, off_gas = 0, off_eua = 0, off_sc = 0;
     std::vector<float> pool32_host;
     int* d_ladder = nullptr;
-    long long* d_dbg = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
@@ -1441,12 +1471,11 @@ HotParams make_hot_params(const ptg_env* h)
     memset(&F, 0, sizeof F);
     F.N = P.N; F.S = P.S; F.sim_step = P.sim_step; F.eps_sim_steps = P.eps_sim_steps; F.F = P.F; F.nT = P.nT; F.tape_len = P.tape_len;
     F.track_changes = P.track_changes; F.key_cold_max = P.key_cold_max; F.key_hot_min = P.key_hot_min; F.key_standby_max = P.key_standby_max;
-    F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride; F.dbg = P.dbg;
+    F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride;
     F.off_featB = h->off_featB; F.off_gasn = h->off_gasn; F.off_euan = h->off_euan; F.off_sc = h->off_sc; F.off_gas = h->off_gas; F.off_eua = h->off_eua;
     F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.noise_sigma = P.noise_sigma; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
     F.recf = P.recf; F.tape = P.tape; F.pool32 = h->d_pool32; F.pool64 = h->d_pool64; F.setc = P.setc; F.argidx = P.argidx;
     F.tabmeta = P.tabmeta; F.ladder = h->d_ladder; F.st_a = P.st_a; F.st_b = P.st_b; F.st_c = P.st_c; F.err = P.err;
-    F.dbg_out = h->d_dbg;
     return F;
 }
 
@@ -1604,7 +1633,6 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     P.F = h->F; P.mod = cfg->raw_modified; P.eps_len_d = cfg->eps_len_d; P.E = 0; P.ep_stride = 0; P.tape_len = 0;
     P.noise_inline = 0; P.noise_seed = 0; P.env_offset = 0; P.noise_sigma = cfg->noise;
     P.track_changes = (cfg->state_change_penalty != 0.0) ? 1 : 0;
-    P.dbg = getenv("PTG_DEBUG_FLAGS") ? atoi(getenv("PTG_DEBUG_FLAGS")) : 0;
     P.t1_start_p_f = cfg->time1_start_p_f; P.t2_start_f_p = cfg->time2_start_f_p; P.t_p_f = cfg->time_p_f; P.t_f_p = cfg->time_f_p;
     P.t1_p_f_p = cfg->time1_p_f_p; P.t2_p_f_p = cfg->time2_p_f_p; P.t3_p_f_p = cfg->time3_p_f_p; P.t34_p_f_p = cfg->time34_p_f_p;
     P.t4_p_f_p = cfg->time4_p_f_p; P.t45_p_f_p = cfg->time45_p_f_p; P.t5_p_f_p = cfg->time5_p_f_p; P.t1_f_p_f = cfg->time1_f_p_f;
@@ -1676,8 +1704,6 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
                                 P.t45_p_f_p, P.t5_p_f_p, P.t1_f_p_f, P.t2_f_p_f, P.t23_f_p_f, P.t3_f_p_f, P.t34_f_p_f, P.t4_f_p_f, P.t45_f_p_f,
                                 P.t5_f_p_f, P.i_full, P.j_full};
         if ((rc = dev_upload(h, &h->d_ladder, lad, LAD_N))) return fail(rc);
-        if ((rc = dev_alloc(h, &h->d_dbg, 64))) return fail(rc);
-        (void)hipMemset(h->d_dbg, 0, 64 * sizeof(long long));
     }
     hipLaunchKernelGGL(k_init_state, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, P, 0, 0);
     if ((rc = launch_check(h, "k_init_state"))) return fail(rc);
@@ -2063,15 +2089,6 @@ int ptg_debug_get_index_lut(ptg_env* h, double* T_values_host, int32_t* lut_host
     *n_T = (int)h->Tvals.size();
     if (T_values_host) memcpy(T_values_host, h->Tvals.data(), sizeof(double) * h->Tvals.size());
     if (lut_host) HIP_TRY(h, hipMemcpy(lut_host, h->P.argidx, sizeof(int) * N_DEST * h->Tvals.size(), hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int ptg_debug_read_counters(ptg_env* h, long long* out64_host)
-{
-    if (!h || !out64_host) return PTG_E_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(out64_host, h->d_dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
