@@ -46,75 +46,85 @@ def check_episode_length(n_gas_train_days, eps_len_d):
     return train_len_d
 
 
-def _electrolyzer_eta(load, cfg):
-    """env/ptg_gym_env.py:311-317 / src/rl_opt.py:84-90 (python float arithmetic, as written there)"""
-    if load < cfg.min_load_electrolyzer:
+def _pem_efficiency(load_fraction, cfg):
+    """LHV efficiency of the PEM electrolyzer at a load fraction (regression polynomial of env/ptg_gym_env.py:311-317,
+    src/rl_opt.py:84-90; Python float arithmetic incl. its `**`, so the value is bit-identical to the reference's)."""
+    x = load_fraction
+    if x < cfg.min_load_electrolyzer:
         return 0.02
-    return (0.598 - 0.325 * load ** 2 + 0.218 * load ** 3 +
-            0.01 * load ** (-1) - 1.68 * 10 ** (-3) * load ** (-2) +
-            2.51 * 10 ** (-5) * load ** (-3))
+    return (0.598 - 0.325 * x ** 2 + 0.218 * x ** 3 +
+            0.01 * x ** (-1) - 1.68 * 10 ** (-3) * x ** (-2) +
+            2.51 * 10 ** (-5) * x ** (-3))
+
+
+def _steady_state_terms(cfg, level):
+    """Price-independent factors of the hourly margin at one steady-state load level (1 = partial, 2 = full load), each a
+    Python float built with the operand order of src/rl_opt.py:57-96 so that products with the price arrays round alike."""
+    ms = cfg.meth_stats_load
+    mol = cfg.convert_mol_to_Nm3
+    b_s3 = 1 if cfg.scenario == 3 else 0
+    n_ch4, n_h2res, n_h2 = ms["Meth_CH4_flow"][level], ms["Meth_H2_res_flow"][level], ms["Meth_H2_flow"][level]
+    m_h2o, p_heat = ms["Meth_H2O_flow"][level], ms["Meth_el_heating"][level]
+    q_ch4 = n_ch4 * mol * cfg.H_u_CH4 * 1000                       # kW_th of methane
+    q_h2res = n_h2res * mol * cfg.H_u_H2 * 1000                    # kW_th of residual hydrogen
+    p_chp = q_ch4 * cfg.eta_CHP * b_s3                             # kW_el of the CHP plant (scenario 3)
+    q_chp = q_ch4 * (1 - cfg.eta_CHP) * b_s3
+    q_steam = m_h2o * (cfg.dt_water * cfg.cp_water + cfg.h_H2O_evap) / 3600
+    v_h2 = n_h2 * mol                                              # Nm3/s of hydrogen
+    eta = _pem_efficiency(v_h2 / cfg.max_h2_volumeflow, cfg)
+    return dict(
+        gas_coef=q_ch4 + q_h2res,                                  # x gas price              -> SNG revenues
+        chp=p_chp * cfg.eeg_el_price,                              # EEG tender revenues
+        steam=(q_steam + q_chp) * cfg.heat_price,
+        oxygen=1 / 2 * v_h2 * 3600 * cfg.o2_price,
+        eua_coef=n_ch4 * cfg.Molar_mass_CO2 / 1000 / 1000 * 3600,  # x EUA price x 100       -> EUA revenues
+        heat_coef=p_heat / 1000,                                   # x electricity price      -> heating costs
+        elz_coef=v_h2 * cfg.H_u_H2 * 1000 / eta,                   # x electricity price      -> electrolysis costs
+        water=(m_h2o + n_h2 * cfg.Molar_mass_H2O / 1000 * 3600) / cfg.rho_water * cfg.water_price)
 
 
 def calculate_optimum(el, gas, eua, cfg):
-    """Potential reward (ct/h) and load identifier per hour, ignoring plant dynamics (src/rl_opt.py:26-152).
+    """Potential reward (ct/h) and load identifier per hour, ignoring plant dynamics (restates src/rl_opt.py:26-152).
 
-    Returns dict(pot_rew, part_full, cum_rew).  Per load level every price-independent factor is a python float
-    computed in the reference's order; the hour loop is replaced by float64 array arithmetic in the same order."""
+    Returns dict(pot_rew, part_full, cum_rew).  The reference loops over hours and the two load levels in Python; here the
+    price-independent factors are scalars (`_steady_state_terms`) and the hour loop is float64 array arithmetic in the same
+    association order, which reproduces the reference's numbers bit for bit (tests/test_prep.py)."""
     el = np.asarray(el, dtype=np.float64)
     gas = np.asarray(gas, dtype=np.float64)
     eua = np.asarray(eua, dtype=np.float64)
-    ms = cfg.meth_stats_load
-    b_s3 = 1 if cfg.scenario == 3 else 0
-    t = np.arange(len(el))
-    t_day = t // 24
-    t_day = np.where(t_day == len(gas), t_day - 1, t_day)          # :51-52
-    gas_t, eua_t = gas[t_day], eua[t_day]
-    rew_l = []
-    for l in range(2):
-        ch4_volumeflow = ms["Meth_CH4_flow"][l + 1] * cfg.convert_mol_to_Nm3
-        h2_res_volumeflow = ms["Meth_H2_res_flow"][l + 1] * cfg.convert_mol_to_Nm3
-        Q_ch4 = ch4_volumeflow * cfg.H_u_CH4 * 1000
-        Q_h2_res = h2_res_volumeflow * cfg.H_u_H2 * 1000
-        ch4_revenues = (Q_ch4 + Q_h2_res) * gas_t
-        power_chp = Q_ch4 * cfg.eta_CHP * b_s3
-        Q_chp = Q_ch4 * (1 - cfg.eta_CHP) * b_s3
-        chp_revenues = power_chp * cfg.eeg_el_price
-        Q_steam = ms["Meth_H2O_flow"][l + 1] * (cfg.dt_water * cfg.cp_water + cfg.h_H2O_evap) / 3600
-        steam_revenues = (Q_steam + Q_chp) * cfg.heat_price
-        h2_volumeflow = ms["Meth_H2_flow"][l + 1] * cfg.convert_mol_to_Nm3
-        o2_volumeflow = 1 / 2 * h2_volumeflow * 3600
-        o2_revenues = o2_volumeflow * cfg.o2_price
-        Meth_CO2_mass_flow = ms["Meth_CH4_flow"][l + 1] * cfg.Molar_mass_CO2 / 1000
-        eua_revenues = Meth_CO2_mass_flow / 1000 * 3600 * eua_t * 100
-        elec_costs_heating = ms["Meth_el_heating"][l + 1] / 1000 * el
-        load_elec = h2_volumeflow / cfg.max_h2_volumeflow
-        eta = _electrolyzer_eta(load_elec, cfg)
-        elec_costs_electrolyzer = h2_volumeflow * cfg.H_u_H2 * 1000 / eta * el
-        elec_costs = elec_costs_heating + elec_costs_electrolyzer
-        water_elec = ms["Meth_H2_flow"][l + 1] * cfg.Molar_mass_H2O / 1000 * 3600
-        water_costs = (ms["Meth_H2O_flow"][l + 1] + water_elec) / cfg.rho_water * cfg.water_price
-        rew_l.append(ch4_revenues + chp_revenues + steam_revenues + eua_revenues + o2_revenues - elec_costs - water_costs)
-    a, b = rew_l
-    full_better = b > a                                            # max() keeps the first maximum (:102-103)
-    rew = np.where(full_better, b, a)
-    index = np.where(full_better, 1, 0)
-    part_full = np.where(rew > 0, index, -1).astype(np.float64)    # :112-135
-    cum_rew = np.cumsum(np.where(rew > 0, rew, 0.0))               # sequential adds like the loop (:125,139)
-    return dict(pot_rew=rew, part_full=part_full, cum_rew=cum_rew)
+    hour = np.arange(len(el))
+    day = np.minimum(hour // 24, len(gas) - 1)                    # the last partial day reuses the last daily price (:51-52)
+    gas_h, eua_h = gas[day], eua[day]
+    margin = []
+    for level in (1, 2):
+        k = _steady_state_terms(cfg, level)
+        revenue_sng = k["gas_coef"] * gas_h
+        revenue_eua = k["eua_coef"] * eua_h * 100
+        cost_el = k["heat_coef"] * el + k["elz_coef"] * el
+        margin.append(revenue_sng + k["chp"] + k["steam"] + revenue_eua + k["oxygen"] - cost_el - k["water"])
+    partial, full = margin
+    full_wins = full > partial                                     # Python's max() keeps the first maximum (:102-103)
+    best = np.where(full_wins, full, partial)
+    part_full = np.where(best > 0, full_wins.astype(np.float64), -1.0)          # -1: no profitable operation (:112-135)
+    cum_rew = np.cumsum(np.where(best > 0, best, 0.0))             # sequential adds like the loop (:125,139)
+    return dict(pot_rew=best, part_full=part_full, cum_rew=cum_rew)
 
 
 def rand_eps_ind(seed_train, n_eps, num_loops, train_len_d, eps_len_d, overhead_factor=10):
-    """src/rl_utils.py:315-335 (global NumPy RandomState seeded with seed_train, one shuffle per loop)."""
-    rs = np.random.RandomState(seed_train)
+    """Order in which training envs visit the n_eps sub-periods of the training set: `overhead_factor * loops` independent
+    random permutations of 0..n_eps-1, concatenated (restates src/rl_utils.py:315-335; the reference seeds NumPy's global
+    legacy generator and shuffles a row per round -- RandomState(seed).shuffle on an equally long array draws the same
+    permutations).  A training set that is one single episode gives all-zero indices."""
     if train_len_d == eps_len_d:
         return np.zeros(n_eps * int(num_loops) * overhead_factor)
-    num_ep = np.linspace(start=0, stop=n_eps - 1, num=n_eps)
-    num_loops_int = 1 if num_loops < 1 else int(num_loops)
-    random_ep = np.zeros((num_loops_int * overhead_factor, n_eps))
-    for i in range(num_loops_int * overhead_factor):
-        random_ep[i, :] = num_ep
-        rs.shuffle(random_ep[i, :])
-    return random_ep.reshape(int(n_eps * num_loops_int * overhead_factor)).astype(int)
+    rounds = (1 if num_loops < 1 else int(num_loops)) * overhead_factor
+    legacy = np.random.RandomState(seed_train)
+    out = np.empty((rounds, n_eps), dtype=int)
+    for r in range(rounds):
+        perm = np.arange(n_eps)
+        legacy.shuffle(perm)
+        out[r] = perm
+    return out.reshape(-1)
 
 
 class Preprocessing:
