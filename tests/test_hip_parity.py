@@ -323,3 +323,49 @@ def test_full_size_properties_n262144_bs3():
         assert np.array_equal(a32.get_state(f), a64.get_state(f)) and np.array_equal(b32.get_state(f), a32.get_state(f)), f
     assert int(rd.sum()) == 0
     a64.close(); a32.close(); b32.close()
+
+
+def test_hot_and_generic_kernels_agree_across_episode_boundaries():
+    """ptg_rollout / ptg_step route non-terminating steps of a synchronised batch to the hot kernels and the terminating step
+    to the generic kernel.  1-day episodes (139 steps), 1000 steps = 7 terminations: identical to the all-generic route,
+    for the fused and the per-step path, float32 row- and feature-major."""
+    import os
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=1, train_steps=200000, state_change_penalty=0.25)
+    n, K = 128, 1000                                      # 7 x 128 finished episodes fit the library's list (>= 1024 entries)
+    rng = np.random.default_rng(9)
+    acts = rng.integers(0, 5, (K, n)).astype(np.int32)
+    results = {}
+    for route in ("hot", "generic"):
+        for layout in ("feature", "row"):
+            if route == "generic":
+                os.environ["PTG_NO_HOT_KERNELS"] = "1"
+            try:
+                eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout=layout)
+                eng.set_episode_plan(spec.eps_ind, n, n)
+                eng.set_noise_rng(3)
+                eng.reset()
+                o, r, d = eng.rollout(acts[:600])
+                eng.sync()
+                outs = [eng.rows(o).cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()]
+                so, sr, sd = [], [], []
+                for t in range(600, K):
+                    oo, rr, dd = eng.step(acts[t])
+                    eng.sync()
+                    so.append(eng.rows(oo).cpu().numpy().copy()); sr.append(rr.cpu().numpy().copy()); sd.append(dd.cpu().numpy().copy())
+                fin = eng.finished_episodes()
+                state = {f: eng.get_state(f) for f in INT_FIELDS + ["act_ep_d", "ep_ptr", "noise_count", "n_state_changes", "cum_rew"]}
+                results[(route, layout)] = (outs, np.array(so), np.array(sr), np.array(sd), fin, state)
+                eng.close()
+            finally:
+                os.environ.pop("PTG_NO_HOT_KERNELS", None)
+    ref = results[("generic", "row")]
+    assert int(ref[0][2].sum()) + int(ref[3].sum()) == 7 * n            # every env terminated seven times
+    for key, res in results.items():
+        for a, b in zip(res[0], ref[0]):
+            assert np.array_equal(a, b), key
+        assert np.array_equal(res[1], ref[1]) and np.array_equal(res[2], ref[2]) and np.array_equal(res[3], ref[3]), key
+        assert sorted(zip(res[4][2].tolist(), res[4][0].tolist())) == sorted(zip(ref[4][2].tolist(), ref[4][0].tolist())), key
+        for f, v in res[5].items():
+            assert np.array_equal(v, ref[5][f]), (key, f)
