@@ -369,3 +369,59 @@ def test_hot_and_generic_kernels_agree_across_episode_boundaries():
         assert sorted(zip(res[4][2].tolist(), res[4][0].tolist())) == sorted(zip(ref[4][2].tolist(), ref[4][0].tolist())), key
         for f, v in res[5].items():
             assert np.array_equal(v, ref[5][f]), (key, f)
+
+
+@pytest.mark.parametrize("sim_step,action_type,raw_modified,out_dtype", [
+    (60, "discrete", "mod", "float32"), (60, "continuous", "raw", "float32"), (300, "discrete", "raw", "float64"),
+    (1200, "continuous", "mod", "float32"), (120, "discrete", "mod", "float32")])
+def test_differential_vs_oracle_other_step_sizes(sim_step, action_type, raw_modified, out_dtype):
+    """Differential test against the CPU oracle for step sizes the golden fixtures do not cover (30, 60, 150, 600 rows per
+    step), toggling partial / full load with short holds so that every rung of both ladders is visited."""
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=4, sim_step=sim_step, raw_modified=raw_modified,
+                             action_type=action_type, train_steps=60 * 8 * (4 * 86400 // sim_step))   # eps_ind long enough for 2 x 2048 draws
+    n, K = 2048, 260
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=out_dtype, obs_layout="feature")
+    eng.set_episode_plan(spec.eps_ind, n, n)
+    eng.fill_noise_tape(seed=sim_step, per_env_len=64)
+    tape = eng.get_noise_tape(64)
+    m = spec.markets[0]
+    consts = dict(spec.consts, scenario=m["scenario"], rew_l_b=m["rew_l_b"], rew_u_b=m["rew_u_b"], r_0=m["r_0"])
+    ora = H.po.OracleVecEnv(consts, spec.tables, dict(m, eps_ind=None if spec.eps_ind is None else spec.eps_ind), n, ep_index0=0)
+    ora.set_noise_tape(tape)
+    rtol, atol = (RTOL64, ATOL64) if out_dtype == "float64" else (RTOL32, ATOL32)
+    # the oracle's construction consumed eps_ind[0:n], its reset takes eps_ind[n + e] -- the plan given to the engine
+    o_ref, _ = ora.reset()
+    np.testing.assert_allclose(eng.rows(eng.reset()).cpu().numpy(), o_ref, rtol=rtol, atol=atol)
+    rng = np.random.default_rng(sim_step)
+    warm = max(3, int(3600 * 2.2 / sim_step))                       # ~2.2 h of startup reaches production from cold
+    hold = rng.integers(1, 12, n)
+    cur = np.full(n, 3)
+    for t in range(K):
+        if t < warm:
+            a = np.full(n, 2)
+        else:
+            flip = (t - warm) % hold == 0
+            cur = np.where(flip, 7 - cur, cur)
+            a = cur.copy()
+            detour = rng.random(n) < 0.01
+            a[detour] = rng.integers(0, 3, int(detour.sum()))
+        if action_type == "continuous":
+            acts = (-1 + 0.4 * (a + 0.5) + rng.uniform(-0.19, 0.19, n)).astype(np.float32)
+        else:
+            acts = a.astype(np.int32)
+        o, r, d = eng.step(acts)
+        eng.sync()
+        o_ref, r_ref, d_ref, _, _ = ora.step(acts)
+        np.testing.assert_allclose(eng.rows(o).cpu().numpy(), o_ref, rtol=rtol, atol=atol, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=rtol, atol=max(atol, 1e-6 if out_dtype == "float32" else 0), err_msg=f"reward step {t}")
+        assert np.array_equal(d.cpu().numpy(), d_ref)
+    ints, f64s = ora.state()
+    for col, name in [(0, "meth_state"), (1, "i"), (2, "j"), (3, "hot_cold"), (4, "standby_tid"), (5, "startup_tid"),
+                      (6, "partial_tid"), (7, "full_tid"), (8, "k"), (9, "current_action"), (11, "act_ep_d")]:
+        assert np.array_equal(eng.get_state(name), ints[:, col]), name
+    assert np.array_equal(eng.get_state("T_cat"), f64s[:, 2])
+    # ladder coverage: every partial-load and full-load table was in use somewhere in the batch
+    assert len(set(eng.get_state("partial_tid").tolist())) >= 3 and len(set(eng.get_state("full_tid").tolist())) >= 3
+    eng.close(); ora.close()
