@@ -287,3 +287,21 @@ class PTGEnv:
 
     def close(self):
         self._vec.close()
+
+
+def sb3_flat_features(obs, raw_modified="mod", price_ahead=13, feature_major=False):
+    """Observation matrix (torch tensor [N, F], or [F, N] with feature_major=True) -> the flat feature tensor SB3's
+    `CombinedExtractor` builds from the dict observation: sub-spaces in sorted key order, every Box flattened, the
+    `Discrete(6)` METH_STATUS one-hot encoded (40 columns for 'mod', 31 for 'raw').  Runs where `obs` lives, so a policy
+    on the same GPU consumes the env's output without a host round trip."""
+    import torch
+    if feature_major:
+        obs = obs.transpose(-1, -2)
+    cols, _ = obs_columns(raw_modified, price_ahead)
+    parts = []
+    for key in sorted(cols):
+        x = obs[..., cols[key]]
+        if key == "METH_STATUS":
+            x = torch.nn.functional.one_hot(x[..., 0].round().long(), num_classes=6).to(obs.dtype)
+        parts.append(x)
+    return torch.cat(parts, dim=-1)

@@ -1,0 +1,67 @@
+"""Host-side logic that needs no GPU: spaces, observation column map, SB3 feature flattening, EnvSpec validation."""
+import numpy as np
+import pytest
+import torch
+
+from rl_ptg_amd.prep import EnvSpec, synthetic_spec
+from rl_ptg_amd.spaces import make_spaces, obs_columns
+from rl_ptg_amd.vec_env import sb3_flat_features
+
+
+def test_spaces_match_reference_declaration():
+    for rm, n_keys, F in (("mod", 11, 35), ("raw", 12, 26)):
+        obs_space, act_space = make_spaces(rm, "discrete")
+        assert len(obs_space.spaces) == n_keys and list(obs_space.spaces) == sorted(obs_space.spaces)
+        assert obs_space["METH_STATUS"].n == 6 and obs_space["T_CAT"].shape == (1,) and obs_space["T_CAT"].dtype == np.float64
+        assert act_space.n == 5
+        cols, width = obs_columns(rm)
+        assert width == F and sorted(cols) == sorted(obs_space.spaces)
+        assert sum(sl.stop - sl.start for sl in cols.values()) == F
+    _, box = make_spaces("mod", "continuous")
+    assert box.shape == (1,) and box.dtype == np.float32 and float(box.low[0]) == -1.0 and float(box.high[0]) == 1.0
+    with pytest.raises(AssertionError):
+        make_spaces("both", "discrete")
+    with pytest.raises(AssertionError):
+        make_spaces("mod", "hybrid")
+
+
+def test_sb3_flat_features_order_and_one_hot():
+    rng = np.random.default_rng(0)
+    n = 7
+    obs = rng.random((n, 35)).astype(np.float32)
+    obs[:, 26] = rng.integers(0, 5, n)
+    flat = sb3_flat_features(torch.from_numpy(obs), "mod").numpy()
+    assert flat.shape == (n, 40)
+    cols, _ = obs_columns("mod")
+    # sorted keys: CH4_syn, Elec_Heating, H2O_DE, H2_in, H2_res, METH_STATUS(6), Part_Full(13), Pot_Reward(13), T_CAT, cos, sin
+    assert np.array_equal(flat[:, 0], obs[:, cols["CH4_syn_MolarFlow"].start])
+    onehot = flat[:, 5:11]
+    assert np.array_equal(onehot.argmax(1), obs[:, 26].astype(int)) and np.all(onehot.sum(1) == 1)
+    assert np.array_equal(flat[:, 11:24], obs[:, cols["Part_Full"]]) and np.array_equal(flat[:, 24:37], obs[:, cols["Pot_Reward"]])
+    assert np.array_equal(flat[:, 38], obs[:, cols["Temp_hour_enc_cos"].start]) and np.array_equal(flat[:, 39], obs[:, cols["Temp_hour_enc_sin"].start])
+    fm = sb3_flat_features(torch.from_numpy(np.ascontiguousarray(obs.T)), "mod", feature_major=True).numpy()
+    assert np.array_equal(fm, flat)
+    raw = sb3_flat_features(torch.zeros((3, 26)), "raw")
+    assert raw.shape == (3, 31)
+
+
+def test_env_spec_validation_and_merge():
+    spec, pre = synthetic_spec(scenario=2, operation="OP2", eps_len_d=32)
+    assert spec.consts["raw_modified"] == 1 and spec.consts["action_type"] == 0 and spec.consts["eps_sim_steps"] == 4608
+    assert spec.eps_ind is not None and len(spec.eps_ind) == 3250 and not spec.eps_ind.any()
+    assert len(spec.markets[0]["el"]) == 38 * 24 and len(spec.markets[0]["gas"]) == 38
+    kw = pre.dict_env_kwargs("val")
+    assert kw["eps_ind"] is None and kw["state_change_penalty"] == 0.0            # validation envs: offset 0, no penalty (:381-385)
+    bad = dict(pre.dict_env_kwargs("train"), raw_modified="both")
+    with pytest.raises(AssertionError):
+        EnvSpec.from_dict_input(bad)
+    bad = dict(pre.dict_env_kwargs("train"), ptg_standby=3)
+    with pytest.raises(ValueError):
+        EnvSpec.from_dict_input(bad)
+    with pytest.raises(ValueError):
+        pre.dict_env_kwargs("holdout")
+    s1, _ = synthetic_spec(scenario=1, operation="OP2", eps_len_d=32)
+    s3, _ = synthetic_spec(scenario=3, operation="OP2", eps_len_d=32)
+    merged = EnvSpec.merge_scenarios([s1, spec, s3])
+    assert [m["scenario"] for m in merged.markets] == [1, 2, 3]
+    assert np.all(merged.markets[1]["gas"] == 15.0) and not merged.markets[2]["gas"].any() and not merged.markets[2]["eua"].any()
