@@ -1216,7 +1216,9 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
                 hour_cur = hour_next;
             }
         }
-        __syncthreads();
+        // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
+        // 39 stores and the producers' record gather just issued -- once per step, which serialises exactly what this kernel overlaps
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (producer && live) {
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
