@@ -722,8 +722,18 @@ __global__ void k_build_fast(const DevParams P, const Rec* __restrict__ in, RecF
 // as 7 dwordx4 (its uniformity tests cost more than the 21 stores it saves), and 32 / 16 envs per wave for more waves per SIMD.
 template <typename T>
 __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) { return *(const T*)((const char*)base + byte_off); }
+// Output rows (observations, rewards, done flags) are written once and never read back by these kernels: non-temporal
+// stores keep the write stream from allocating in L2, where it evicts the window records and market series every step
+// re-reads (measured at N = 65 536: 2.86 -> 1.90 us per fused step, and the producer / consumer form 2.96 -> 1.51).
 template <typename T>
-__device__ __forceinline__ void st_off(void* base, unsigned byte_off, T v) { *(T*)((char*)base + byte_off) = v; }
+__device__ __forceinline__ void st_off(void* base, unsigned byte_off, T v)
+{
+#ifdef PTG_PLAIN_STORES
+    *(T*)((char*)base + byte_off) = v;
+#else
+    __builtin_nontemporal_store(v, (T*)((char*)base + byte_off));
+#endif
+}
 
 enum { LAD_T1_START_P_F = 0, LAD_T2_START_F_P, LAD_T_P_F, LAD_T_F_P, LAD_T1_P_F_P, LAD_T2_P_F_P, LAD_T3_P_F_P, LAD_T34_P_F_P,
        LAD_T4_P_F_P, LAD_T45_P_F_P, LAD_T5_P_F_P, LAD_T1_F_P_F, LAD_T2_F_P_F, LAD_T23_F_P_F, LAD_T3_F_P_F, LAD_T34_F_P_F,
@@ -927,6 +937,8 @@ struct HotRow {                  // observation row addressing: uniform base + 3
     __device__ __forceinline__ HotRow(float* b, const HotParams& P, int e)
         : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u) {}
     __device__ __forceinline__ void put(int q, float v) const { st_off<float>(base, boff + (unsigned)q * qbytes, v); }
+    // same address as (uniform pointer advanced by SALU) + (the one lane offset): no per-feature offset registers
+    __device__ __forceinline__ void put_u(int q, float v) const { st_off<float>(base + (size_t)q * qbytes, boff, v); }
 };
 
 template <bool FM, bool MOD>
@@ -1072,39 +1084,106 @@ k_rollout_hot(const HotParams P, const void* __restrict__ actions, int k0, int T
 }
 
 
-// Producer / consumer form of the fused rollout.  Half of every workgroup's waves (producers) run the state machine, the
-// record gather and the reward for one env per lane and hand each step's per-env results {METH_STATUS, six plant features,
-// reward} to the other half (consumers) through a double-buffered LDS slot.  The consumers own everything that does not
-// depend on the state machine: the 26 market features (a function of the hour only -- reloaded when the hour changes, i.e.
-// every 3600 / sim_step steps, one step ahead of use), the two clock features (scalar loads: the step count is uniform),
-// and ALL stores of the step.  Two waves per SIMD: the store stream of step t-1 overlaps the dependent instruction chain
-// of step t.  One barrier per step.
-struct PcSlot {                  // structure of arrays: consecutive lanes hit consecutive banks
-    float s[256], feat[6][256], rew[256];
+// Producer / consumer form of the fused rollout ("split gather").  Half of every workgroup's waves (producers) run ONLY the
+// integer state machine: its loop-carried dependence on memory is the temperature key of the window just entered, so the
+// producers gather 2 bytes per env and step (rkey[], the keys of all window records as one uint16 array) and hand
+// {record index, METH_STATUS, state-changed} to the other half as one LDS word.  The consumers own everything that is not on
+// that chain: the 64-byte record gather, the reward and cum_rew, the 26 market features and three prices (functions of the
+// hour -- reloaded when the hour changes, one step ahead of use), the clock features (scalar loads: the step count is
+// uniform) and ALL stores.  A consumer issues the gather of step t, then finishes step t-1 (whose record was requested one
+// iteration earlier), so no wave ever waits on a load it has just issued.  One LDS-only barrier per step.
+struct PcSlot { unsigned w[256]; };      // record index | METH_STATUS << 24 | changed << 27
+
+struct PcMarket {
+    float fa[13], fb[13];
+    double el, gas, eua;
 };
 
-template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT>
+template <bool MOD>
+__device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4, unsigned db4, PcMarket& M)
+{
+    const float* pA = P.pool32;
+#pragma unroll
+    for (int q = 0; q < 13; q++) M.fa[q] = ld_off<float>(pA + q, hb4);
+    if (MOD) {
+        const float* pB = P.pool32 + P.off_featB;
+#pragma unroll
+        for (int q = 0; q < 13; q++) M.fb[q] = ld_off<float>(pB + q, hb4);
+    } else {
+        const float* pG = P.pool32 + P.off_gasn;
+        const float* pU = P.pool32 + P.off_euan;
+        M.fb[0] = ld_off<float>(pG, db4); M.fb[1] = ld_off<float>(pG + 1, db4);
+        M.fb[2] = ld_off<float>(pU, db4); M.fb[3] = ld_off<float>(pU + 1, db4);
+    }
+    M.el = ld_off<double>(P.pool64, hb4 * 2u);
+    M.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
+    M.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
+}
+
+template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT, bool FULL>
 __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
-             uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
+             uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     HotLds& L = *(HotLds*)s_dyn;
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
-    unsigned short* s_lut = (unsigned short*)((unsigned char*)slot + 2 * sizeof(PcSlot));
-    const int NP = blockDim.x / 2;                          // envs per workgroup (<= 256)
-    const bool producer = (int)threadIdx.x < NP;
+    const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256)
+    unsigned char* s_act = (unsigned char*)slot + 2 * sizeof(PcSlot);                    // [T][NP] decoded actions of the launch
+    unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
+    const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
     const int lx = producer ? threadIdx.x : threadIdx.x - NP;
-    const int e_raw = blockIdx.x * NP + lx;
-    const bool live = e_raw < P.N;
+    const int e_raw = e_base + blockIdx.x * NP + lx;        // this launch covers envs [e_base, e_base + gridDim.x * NP)
+    // FULL: the batch fills every workgroup -- no divergent region around the stores, so the backend's vmcnt bookkeeping stays
+    // exact (a skipped-stores path makes it assume the worst and drain the queue every step)
+    const bool live = FULL || e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
     const StA a = P.st_a[e]; const StB b = P.st_b[e];
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
-    int ri = 0, ni = 0; float rf = 0.f, nf = 0.f;
-    if (producer) {
-        hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
-        if (T > 1) hot_fetch<ACTK>(actions, (size_t)P.N + e, ni, nf);
+    // The whole launch's action rows are staged into LDS up front, decoded to one byte each (7 = "keep the previous action":
+    // no threshold fired, :351-355, or an invalid discrete action, which also raises the error flag).  A fresh action row
+    // comes from HBM; fetched step by step its latency under the write stream -- vmcnt retires in order, so one slow load holds
+    // back every younger one -- cost more than the whole rest of the step (2.9 vs 1.55 us per step at N = 65 536).
+    {
+        const int sh_np = __ffs(NP) - 1, total = T << sh_np;
+        const int e_wg = e_base + blockIdx.x * NP;
+        auto code_of = [&](int ri, float rf) -> int {
+            if (ACTK == PTG_ACT_F32) return decode_continuous(rf, 7);
+            const bool bad = (ri < -5) | (ri > 4);
+            if (__ballot(bad)) { if (bad) atomicOr(P.err, 1); }
+            return bad ? 7 : (ri < 0 ? ri + 5 : ri);
+        };
+        if (FULL && vec_rows) {          // four envs per lane: one dwordx4 (two for int64 actions) per quad, one packed LDS word
+#pragma unroll 16
+            for (int q4 = threadIdx.x; q4 < (total >> 2); q4 += blockDim.x) {
+                const int idx = q4 << 2, t = idx >> sh_np, x = idx & (NP - 1);
+                const size_t g = (size_t)t * P.N + e_wg + x;
+                int c[4];
+                if (ACTK == PTG_ACT_I64) {
+                    const longlong2 v0 = *(const longlong2*)((const long long*)actions + g), v1 = *(const longlong2*)((const long long*)actions + g + 2);
+                    const long long v[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) c[j] = code_of((v[j] < -5 || v[j] > 4) ? 99 : (int)v[j], 0.f);
+                } else if (ACTK == PTG_ACT_F32) {
+                    const float4 v = *(const float4*)((const float*)actions + g);
+                    c[0] = code_of(0, v.x); c[1] = code_of(0, v.y); c[2] = code_of(0, v.z); c[3] = code_of(0, v.w);
+                } else {
+                    const int4 v = *(const int4*)((const int*)actions + g);
+                    c[0] = code_of(v.x, 0.f); c[1] = code_of(v.y, 0.f); c[2] = code_of(v.z, 0.f); c[3] = code_of(v.w, 0.f);
+                }
+                *(unsigned*)(s_act + idx) = (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16) | ((unsigned)c[3] << 24);
+            }
+        } else {
+#pragma unroll 8
+            for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+                const int t = idx >> sh_np, x = idx & (NP - 1);
+                const int eg = min(e_wg + x, P.N - 1);
+                int ri = 0; float rf = 0.f;
+                hot_fetch<ACTK>(actions, (size_t)t * P.N + eg, ri, rf);
+                s_act[idx] = (unsigned char)code_of(ri, rf);
+            }
+        }
     }
     hot_stage_lds(P, L);
     if (LDSLUT) {
@@ -1116,115 +1195,133 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     __syncthreads();
     const unsigned short* lut = LDSLUT ? s_lut : nullptr;
     const unsigned mset = (R.flags >> 15) & 3;
-    HotLoads Q;                                             // producer: loads of the step in flight; consumer: current market features
-    HotLoads Qn;                                            // consumer: market features of the next hour
-    double2 setc = make_double2(0.0, 0.0);
     // series offsets of step count k1 for this env (:442-447); uniform except for the episode offset
     auto offsets = [&](int k1, unsigned& hb4, unsigned& db4) {
         const int secs = k1 * P.sim_step;
         int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
-        H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2));      // range errors are flagged by the producers
+        const bool oob = (H + 13 > P.n_hours) | (D + 2 > P.n_days) | (H < 0) | (D < 0);
+        if (__ballot(oob)) {
+            if (oob) { atomicOr(P.err, 2); H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
+        }
         hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u;
         db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
     };
+    PcMarket M, Mn;                                         // consumer: market data of the step being finished / of the next hour
+    double2 setc = make_double2(0.0, 0.0);
     int hour_cur = 0;
-    if (producer) {
+    unsigned tk = 0;                                        // producer: key of the window entered by the previous step (in flight)
+    RecFast recA, recB; unsigned wA = 0, wB = 0;            // consumer: records in flight (ping-pong: no copies of pending loads)
+    if (!producer) {
         setc = P.setc[mset];
-        hot_front<MOD, NOISE, false>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, k0 + 1, Q);   // front half of step 0
-    } else {
-        offsets(k0 + 1, Q.hb4, Q.db4);
-        Q.kk8 = 0;
+        unsigned hb4, db4;
+        offsets(k0 + 1, hb4, db4);
         hour_cur = ((k0 + 1) * P.sim_step) / 3600;
-        const float* pA = P.pool32;
-#pragma unroll
-        for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<float>(pA + q, Q.hb4);
-        if (MOD) {
-            const float* pB = P.pool32 + P.off_featB;
-#pragma unroll
-            for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<float>(pB + q, Q.hb4);
-        } else {
-            const float* pG = P.pool32 + P.off_gasn;
-            const float* pU = P.pool32 + P.off_euan;
-            Q.fb[0] = ld_off<float>(pG, Q.db4); Q.fb[1] = ld_off<float>(pG + 1, Q.db4);
-            Q.fb[2] = ld_off<float>(pU, Q.db4); Q.fb[3] = ld_off<float>(pU + 1, Q.db4);
-        }
+        pc_load_market<MOD>(P, hb4, db4, M);
     }
     const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
-    char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of step it-1
-    for (int it = 0; it <= T; it++) {
-        if (producer) {
-            if (it < T) {
-                PcSlot& S = slot[it & 1];
-                const float r = hot_back(P, R, Q, setc, e, live);
-                S.s[lx] = (float)(R.flags & 7);
+    char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of the step being finished
+    // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
+    // stores and the gathers just issued -- once per step, which serialises exactly what this kernel overlaps
+    auto handoff = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto produce = [&](const int it) {                      // state machine of step `it`
+        if (it > 0) R.flags = (R.flags & 0x1FFFFu) | (tk << 17);                  // Meth_T_cat = op[-1, 1] (:452)
+        const int code = s_act[it * NP + lx];
+        const int act = (code == 7) ? (int)((R.flags >> 12) & 7) : code;
+        bool changed;
+        const int ridx = hot_ints<NOISE>(P, L, lut, LDSLUT, R, act, e, changed);
+        tk = ld_off<unsigned short>(rkey, (unsigned)ridx * 2u);
+        slot[it & 1].w[lx] = (unsigned)ridx | ((R.flags & 7u) << 24) | (changed ? (1u << 27) : 0u);
+    };
+    auto request = [&](const int t, RecFast& rec, unsigned& w) {                  // consumer: record gather of step t
+        w = slot[t & 1].w[lx];
+        rec = ld_off<RecFast>(P.recf, (w & 0xFFFFFFu) * 64u);
+    };
+    // consumer: finish step t (record already requested), optionally requesting step t+1 in between.  Issue order = retire
+    // order (vmcnt): clock + next-hour loads, then the gather, then the stores -- nothing the stores need sits behind the gather
+    auto finish = [&](const int t, const RecFast& rec, const unsigned w, const bool more, RecFast& recN, unsigned& wN) {
+        const int k1 = k0 + t + 1;
+        const int hour_next = ((k1 + 1) * P.sim_step) / 3600;
+        const bool reload = (hour_next != hour_cur) && (t + 1 < T);
+        const float2 sc = ld_off<float2>(P.pool32 + P.off_sc, (unsigned)min(k1, P.eps_sim_steps) * 8u);
+        if (reload) {                                       // uniform branch
+            unsigned hb4, db4;
+            offsets(k1 + 1, hb4, db4);
+            pc_load_market<MOD>(P, hb4, db4, Mn);
+        }
+        if (more) request(t + 1, recN, wN);
+        const bool changed = (w >> 27) & 1u;
+        double rw = rec.base + rec.ch4 * (setc.x * P.k_chp + P.k_eua * M.eua) + rec.c_gas * M.gas - rec.c_el * M.el;
+        R.cum += rw;
+        rw -= changed ? setc.y : 0.0;                                            // :332
+        if (P.track_changes) { if (changed && live) P.st_c[e].nchg += 1; }
+        if (live) {
+            const HotRow<FM> row((float*)obs_t, P, e);
 #pragma unroll
-                for (int q = 0; q < 6; q++) S.feat[q][lx] = Q.rec.feat[q];
-                S.rew[lx] = r;
-                if (it + 1 < T) {
-                    const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
-                    if (it + 2 < T) hot_fetch<ACTK>(actions, (size_t)(it + 2) * P.N + e, ni, nf);
-                    hot_front<MOD, NOISE, false>(P, L, lut, LDSLUT, R, act, e, k0 + it + 2, Q);
-                }
+            for (int q = 0; q < 13; q++) row.put_u(q, M.fa[q]);
+#pragma unroll
+            for (int q = 0; q < (MOD ? 13 : 4); q++) row.put_u(13 + q, M.fb[q]);
+            constexpr int o = MOD ? 26 : 17;
+            row.put_u(o + 0, (float)((w >> 24) & 7u));
+#pragma unroll
+            for (int q = 0; q < 6; q++) row.put_u(o + 1 + q, rec.feat[q]);
+            st_off<float>(rew_t, (unsigned)e * 4u, (float)rw);
+            st_off<uint8_t>(done_t, (unsigned)e, 0);
+            row.put_u(o + 7, sc.x);
+            row.put_u(o + 8, sc.y);
+        }
+        obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
+        if (reload) { M = Mn; hour_cur = hour_next; }
+    };
+    // iteration `it`: producers run step it (while it < T); consumers request step it-1 and finish step it-2.  The two roles
+    // run SEPARATE loops with the same number (T + 1) of barriers: the role is wave-uniform, and with one role per loop the
+    // backend's vmcnt bookkeeping sees only that role's loads and stores (a shared loop with the roles as exec-masked regions
+    // made it drain the whole queue at the top of every consumer iteration).
+    if (producer) {
+        for (int it = 0; it < T; it++) { produce(it); handoff(); }
+        handoff();
+    } else {
+        handoff();
+        request(0, recA, wA);
+        handoff();
+        if (T == 1) {
+            finish(0, recA, wA, false, recB, wB);
+        } else {
+            // the first finish is peeled so that the loop is entered in the state its back edge leaves (a gather followed by
+            // a step's stores): the backend then derives the exact vmcnt for "record landed", not the prologue's small one
+            finish(0, recA, wA, true, recB, wB);
+            handoff();
+            int it = 3;
+            for (; it + 1 <= T; it += 2) {                  // two steps per trip: the records ping-pong, no register copies
+                finish(it - 2, recB, wB, true, recA, wA);
+                handoff();
+                finish(it - 1, recA, wA, true, recB, wB);
+                handoff();
             }
-        } else if (it >= 1) {
-            // step t = it-1 has step count k1 = k0 + it; the NEXT step's hour decides whether new market features are fetched now
-            const int k1 = k0 + it;
-            const int hour_next = ((k1 + 1) * P.sim_step) / 3600;
-            const bool reload = (hour_next != hour_cur) && (it < T);
-            if (reload) {                                   // uniform branch; loads issued BEFORE this step's stores
-                offsets(k1 + 1, Qn.hb4, Qn.db4);
-                const float* pA = P.pool32;
-#pragma unroll
-                for (int q = 0; q < 13; q++) Qn.fa[q] = ld_off<float>(pA + q, Qn.hb4);
-                if (MOD) {
-                    const float* pB = P.pool32 + P.off_featB;
-#pragma unroll
-                    for (int q = 0; q < 13; q++) Qn.fb[q] = ld_off<float>(pB + q, Qn.hb4);
-                } else {
-                    const float* pG = P.pool32 + P.off_gasn;
-                    const float* pU = P.pool32 + P.off_euan;
-                    Qn.fb[0] = ld_off<float>(pG, Qn.db4); Qn.fb[1] = ld_off<float>(pG + 1, Qn.db4);
-                    Qn.fb[2] = ld_off<float>(pU, Qn.db4); Qn.fb[3] = ld_off<float>(pU + 1, Qn.db4);
-                }
-            }
-            const float2 sc = ((const float2*)(P.pool32 + P.off_sc))[min(k1, P.eps_sim_steps)];     // uniform index: scalar load
-            const PcSlot& S = slot[(it - 1) & 1];
-            const float sv = S.s[lx];
-            float ft[6];
-#pragma unroll
-            for (int q = 0; q < 6; q++) ft[q] = S.feat[q][lx];
-            const float r = S.rew[lx];
-            if (live) {
-                const HotRow<FM> row((float*)obs_t, P, e);
-#pragma unroll
-                for (int q = 0; q < 13; q++) row.put(q, Q.fa[q]);
-#pragma unroll
-                for (int q = 0; q < (MOD ? 13 : 4); q++) row.put(13 + q, Q.fb[q]);
-                constexpr int o = MOD ? 26 : 17;
-                row.put(o + 0, sv);
-#pragma unroll
-                for (int q = 0; q < 6; q++) row.put(o + 1 + q, ft[q]);
-                row.put(o + 7, sc.x);
-                row.put(o + 8, sc.y);
-                st_off<float>(rew_t, (unsigned)e * 4u, r);
-                st_off<uint8_t>(done_t, (unsigned)e, 0);
-            }
-            obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
-            if (reload) {
-#pragma unroll
-                for (int q = 0; q < 13; q++) { Q.fa[q] = Qn.fa[q]; Q.fb[q] = Qn.fb[q]; }
-                hour_cur = hour_next;
+            if (it <= T) {                                  // it == T: one request left
+                finish(it - 2, recB, wB, true, recA, wA);
+                handoff();
+                finish(T - 1, recA, wA, false, recB, wB);
+            } else {
+                finish(T - 1, recB, wB, false, recA, wA);
             }
         }
-        // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
-        // 39 stores and the producers' record gather just issued -- once per step, which serialises exactly what this kernel overlaps
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (producer && live) {
-        StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
-        StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
-        P.st_a[e] = na; P.st_b[e] = nb;
+    if (live) {
+        if (producer) {
+            R.flags = (R.flags & 0x1FFFFu) | (tk << 17);
+            StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
+            P.st_a[e] = na;
+            *(int2*)((char*)&P.st_b[e] + 8) = make_int2(R.act_d, R.nctr);
+        } else {
+            *(double*)&P.st_b[e] = R.cum;
+        }
     }
+}
+
+__global__ void k_extract_keys(const RecFast* __restrict__ recf, unsigned short* __restrict__ rkey, int n)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) rkey[g] = (unsigned short)recf[g].tkey;
 }
 
 }  // namespace
@@ -1242,6 +1339,7 @@ struct ptg_env {
     bool fast = false, fm = false;
     double* d_tape = nullptr;
     unsigned short* d_lut16 = nullptr;
+    unsigned short* d_rkey = nullptr;   // temperature keys of all window records (k_rollout_pc producers)
     float* d_pool32 = nullptr; double* d_pool64 = nullptr;
     unsigned off_featB = 0, off_gasn = 0, off_euan = 0, off_gas = 0, off_eua = 0, off_sc = 0;
     std::vector<float> pool32_host;
@@ -1504,24 +1602,49 @@ template <bool FM, bool MOD, int NOISE>
 void launch_rollout_pc(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
-    int bs = 128;                                           // half producers, half consumers; >= 256 workgroups when possible
-    while (bs < 512 && (long long)grid_for(h->n, bs) >= 256) bs *= 2;     // bs/2 envs per workgroup
-    if (getenv("PTG_BLOCK")) bs = atoi(getenv("PTG_BLOCK"));
-    const dim3 grid(grid_for(h->n, bs / 2)), block(bs);
-    const size_t l_bytes = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);
+    // One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many steps as its LDS action stage holds;
+    // larger batches / longer rollouts run as consecutive launches over env slices and step segments.
+    int chunk = getenv("PTG_PC_CHUNK") ? atoi(getenv("PTG_PC_CHUNK")) : 65536;
+    chunk = std::max(256, chunk / 256 * 256);
+    const size_t asz = kind == PTG_ACT_I64 ? 8 : 4;
+    const size_t fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);
     const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
-    const bool ll = h->d_lut16 && l_bytes + lut_bytes <= 160000 && !getenv("PTG_NO_LDS_LUT");
-    const size_t sh = l_bytes + (ll ? lut_bytes : 0);
-#define PTG_PC(ACTK, LL)                                                                                              \
+    const size_t lds_max = 160 * 1024 - 512;
+    int bs_all = 128;                                       // half producers, half consumers; >= 256 workgroups when possible
+    while (bs_all < 512 && (long long)grid_for(std::min(chunk, h->n), bs_all) >= 256) bs_all *= 2;     // bs/2 envs per workgroup
+    if (getenv("PTG_BLOCK")) bs_all = atoi(getenv("PTG_BLOCK"));
+    const int np = bs_all / 2;
+    // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
+    const bool ll = h->d_lut16 && fixed + lut_bytes + (size_t)64 * np + 64 <= lds_max && !getenv("PTG_NO_LDS_LUT");
+    const size_t avail = lds_max - fixed - (ll ? lut_bytes : 0) - 64;
+    const int t_cap = (int)std::min<size_t>(512, avail / np);
+    for (int ts = 0; ts < T; ts += t_cap) {
+        const int tn = std::min(t_cap, T - ts);
+        const char* a_s = (const char*)actions + (size_t)ts * h->n * asz;
+        float* o_s = obs + (size_t)ts * h->n * h->F;
+        float* r_s = rew + (size_t)ts * h->n;
+        uint8_t* d_s = done + (size_t)ts * h->n;
+        const int k0 = h->sync_k + ts;
+        const int vec_rows = (h->n % 4 == 0) && ((uintptr_t)a_s % 16 == 0) && (chunk % 4 == 0);     // whole-row vector loads are aligned
+        const size_t sh = fixed + 16 * (((size_t)tn * np + 15) / 16) + (ll ? lut_bytes : 0);
+        for (int e0 = 0; e0 < h->n; e0 += chunk) {
+            const int m = std::min(chunk, h->n - e0);
+            const dim3 grid(grid_for(m, np)), block(bs_all);
+            const bool full = m % np == 0;
+#define PTG_PC2(ACTK, LL, FULL)                                                                                       \
     do {                                                                                                              \
-        auto kfn = k_rollout_pc<FM, MOD, NOISE, ACTK, LL>;                                                            \
-        if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16);                    \
+        auto kfn = k_rollout_pc<FM, MOD, NOISE, ACTK, LL, FULL>;                                                      \
+        if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); \
+        hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
     } while (0)
-    if (kind == PTG_ACT_F32) { if (ll) PTG_PC(PTG_ACT_F32, true); else PTG_PC(PTG_ACT_F32, false); }
-    else if (kind == PTG_ACT_I64) { if (ll) PTG_PC(PTG_ACT_I64, true); else PTG_PC(PTG_ACT_I64, false); }
-    else { if (ll) PTG_PC(PTG_ACT_I32, true); else PTG_PC(PTG_ACT_I32, false); }
+#define PTG_PC(ACTK, LL) do { if (full) PTG_PC2(ACTK, LL, true); else PTG_PC2(ACTK, LL, false); } while (0)
+            if (kind == PTG_ACT_F32) { if (ll) PTG_PC(PTG_ACT_F32, true); else PTG_PC(PTG_ACT_F32, false); }
+            else if (kind == PTG_ACT_I64) { if (ll) PTG_PC(PTG_ACT_I64, true); else PTG_PC(PTG_ACT_I64, false); }
+            else { if (ll) PTG_PC(PTG_ACT_I32, true); else PTG_PC(PTG_ACT_I32, false); }
 #undef PTG_PC
+#undef PTG_PC2
+        }
+    }
 }
 
 template <bool FM, bool MOD, int NOISE>
@@ -1689,6 +1812,9 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         hipLaunchKernelGGL(k_build_fast, dim3(grid_for((long long)h->rec_total, 256)), dim3(256), 0, 0, P, P.rec, d_recf, (int)h->rec_total);
         if ((rc = launch_check(h, "k_build_fast"))) return fail(rc);
         P.recf = d_recf;
+        if ((rc = dev_alloc(h, &h->d_rkey, h->rec_total + 8))) return fail(rc);
+        hipLaunchKernelGGL(k_extract_keys, dim3(grid_for((long long)h->rec_total, 256)), dim3(256), 0, 0, d_recf, h->d_rkey, (int)h->rec_total);
+        if ((rc = launch_check(h, "k_extract_keys"))) return fail(rc);
     }
 
     if ((rc = dev_alloc(h, &P.st_a, n_envs)) || (rc = dev_alloc(h, &P.st_b, n_envs)) || (rc = dev_alloc(h, &P.st_c, n_envs)))

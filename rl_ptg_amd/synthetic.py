@@ -34,10 +34,17 @@ def sticky_actions_device(n_steps, n_envs, seed, device, p_switch=1.0 / 12.0):
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     out = torch.empty((n_steps, n_envs), dtype=torch.int32, device=device)
-    cur = torch.randint(0, 5, (n_envs,), generator=g, device=device, dtype=torch.int32)
-    for t in range(n_steps):
-        sw = torch.rand((n_envs,), generator=g, device=device) < p_switch
-        new = torch.randint(0, 5, (n_envs,), generator=g, device=device, dtype=torch.int32)
-        cur = torch.where(sw, new, cur)
-        out[t] = cur
+    if n_steps == 0 or n_envs == 0:
+        return out
+    # a handful of launches per column block instead of five per step: held actions = the draw at the latest switch time
+    # (forward fill through a running maximum of the switch times)
+    block = max(1, (1 << 26) // n_steps)
+    t_idx = torch.arange(n_steps, device=device).unsqueeze(1)
+    for c0 in range(0, n_envs, block):
+        m = min(block, n_envs - c0)
+        sw = torch.rand((n_steps, m), generator=g, device=device) < p_switch
+        sw[0] = True
+        new = torch.randint(0, 5, (n_steps, m), generator=g, device=device, dtype=torch.int32)
+        last = torch.cummax(torch.where(sw, t_idx, torch.zeros_like(t_idx)), dim=0).values
+        out[:, c0:c0 + m] = torch.gather(new, 0, last)
     return out

@@ -1,0 +1,39 @@
+"""Per-segment device time of consecutive fused rollouts from reset: python tools/timecourse.py [envs] [segments] [steps_per_segment]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rl_ptg_amd import dist as ptg_dist
+from rl_ptg_amd.engine import HipEngine
+from rl_ptg_amd.prep import synthetic_spec
+from rl_ptg_amd.synthetic import sticky_actions_device
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+segs = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+dev = torch.device("cuda", 0)
+spec, _ = synthetic_spec(scenario=int(os.environ.get("TC_SCEN", "1")), operation=os.environ.get("TC_OP", "OP1"), eps_len_d=32)
+first_ptr, stride = ptg_dist.episode_plan(n, 1, 0)
+eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="feature")
+eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
+eng.set_noise_rng(seed=20250614)
+actions = sticky_actions_device(segs * S, n, seed=1234, device=dev, p_switch=1.0 / 12.0)
+eng.reset()
+F = eng.obs_dim
+obs = torch.empty((S, F, n), dtype=torch.float32, device=dev)
+rew = torch.empty((S, n), dtype=torch.float32, device=dev)
+done = torch.empty((S, n), dtype=torch.uint8, device=dev)
+out = []
+for s in range(segs):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    a0 = 0 if os.environ.get("TC_REUSE") else s * S          # TC_REUSE: every segment replays the first (cache-resident) action rows
+    eng.rollout(actions[a0:a0 + S], obs, rew, done)
+    e1.record()
+    torch.cuda.synchronize()
+    import numpy as np
+    st = eng.get_state("meth_state")
+    hist = np.bincount(st, minlength=5) / n
+    hist = np.append(hist, [len(np.unique(eng.get_state("i"))), len(np.unique(eng.get_state("T_cat")))])
+    out.append((s * S, e0.elapsed_time(e1) * 1e3 / S, hist))
+for t0, us, hist in out:
+    print("steps %5d.. us/step %.3f  state mix %s" % (t0, us, " ".join("%.2f" % h for h in hist)))
