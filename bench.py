@@ -72,8 +72,8 @@ def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--path", choices=["step", "rollout"], default="rollout",
                     help="timed path: ptg_rollout (K steps fused in one launch) or ptg_step (one launch per step); the other one is "
@@ -163,6 +163,7 @@ def main():
                     run(W, K)
             torch.cuda.current_stream(device).wait_stream(side)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_launch = eng.rollout_launches(K) if path == "rollout" else K        # kernel launches inside the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -186,25 +187,24 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed, dev_ms = float(tmax[0]), float(tmax[1])
         eng.close()
-        return elapsed, dev_ms, len(r_all)
+        return elapsed, dev_ms, len(r_all), n_launch
 
-    def roofline(path, dev_ms, out_bytes):
+    def roofline(path, dev_ms, out_bytes, launches):
         b_alg = algorithmic_bytes_per_env_step(F, out_bytes, path)
-        launches = 1 if path == "rollout" else K
         per_launch_s = dev_ms * 1e-3 / launches
-        bytes_per_launch = b_alg * n * (K if path == "rollout" else 1)
+        bytes_per_launch = b_alg * n * K / launches           # a rollout launch covers K / launches steps (of <= 65 536 envs each)
         achieved = bytes_per_launch / per_launch_s / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "kernel": "k_step_hot" if path == "step" else "k_rollout_hot",
+                "traffic": None, "kernel": "k_step_hot" if path == "step" else "k_rollout_pc",
                 "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches}
 
-    elapsed, dev_ms, n_fin = measure(args.path, args.launch)
+    elapsed, dev_ms, n_fin, n_launch = measure(args.path, args.launch)
     other = "rollout" if args.path == "step" else "step"
-    o_elapsed, o_dev_ms, _ = measure(other, args.launch) if args.also else (None, None, None)
+    o_elapsed, o_dev_ms, _, o_launch = measure(other, args.launch) if args.also else (None, None, None, None)
 
     if rank == 0:
         out_bytes = 4 if args.out_dtype == "float32" else 8
-        roof = roofline(args.path, dev_ms, out_bytes)
+        roof = roofline(args.path, dev_ms, out_bytes, n_launch)
         tj = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and n == 65536 and args.out_dtype == "float32" and args.obs_layout == "feature":
@@ -213,13 +213,15 @@ def main():
             except Exception:
                 tj = {}
 
+        n_launch_of = {args.path: n_launch, other: o_launch}
+
         def traffic(path):                            # HBM bytes per launch, like `achieved`
             if path == "step":
                 return tj.get("step_bytes_per_launch")
-            return tj["rollout_bytes_per_step"] * K if "rollout_bytes_per_step" in tj else None
+            return tj["rollout_bytes_per_step"] * K / n_launch_of[path] if "rollout_bytes_per_step" in tj else None
         roof["traffic"] = traffic(args.path)
         path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
-                     "rollout": "ptg_rollout, K steps fused in one launch"}
+                     "rollout": f"ptg_rollout, K steps fused ({n_launch_of['rollout']} kernel launch(es): <= 65536 envs x <= ~445 steps each)"}
         line = {
             "metric": "env-steps/sec at N=65536 envs; achieved HBM GB/s vs roofline",
             "value": n_total * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -234,7 +236,7 @@ def main():
         }
         if o_elapsed is not None:
             line["also"] = {"path": path_name[other], "value": n_total * K / o_elapsed, "unit": "env-steps/s",
-                            "ms_per_step": o_elapsed * 1e3 / K, "roofline": dict(roofline(other, o_dev_ms, out_bytes), traffic=traffic(other))}
+                            "ms_per_step": o_elapsed * 1e3 / K, "roofline": dict(roofline(other, o_dev_ms, out_bytes, o_launch), traffic=traffic(other))}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))

@@ -155,10 +155,14 @@ int ptg_reset(ptg_env* env, const uint8_t* mask_host, void* obs_dev, void* strea
  *   info_dev     [N][24] (nullable, float64) _get_info (:251-278) in key order, Meth_Action as its index */
 int ptg_step(ptg_env* env, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev,
              uint8_t* done_dev, void* final_obs_dev, double* info_dev, void* stream);
-/* T vector steps in one launch, state held in registers: actions [T][N] -> obs [T][N][F], rew [T][N], done [T][N].
- * Same results as T calls of ptg_step. */
+/* T vector steps fused, state held in registers: actions [T][N] -> obs [T][N][F], rew [T][N], done [T][N].
+ * Same results as T calls of ptg_step.  One kernel launch covers up to 65 536 envs and as many steps as fit its LDS action
+ * stage (a few hundred); wider batches / longer rollouts are issued as consecutive launches on `stream`. */
 int ptg_rollout(ptg_env* env, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
                 uint8_t* done_dev, void* stream);
+/* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
+ * per-launch timing); negative PTG_E_* on a bad argument. */
+int ptg_rollout_launches(ptg_env* env, int n_steps);
 /* hipStreamSynchronize(stream) + report an error a kernel flagged (PTG_E_ACTION / PTG_E_RANGE). */
 int ptg_sync(ptg_env* env, void* stream);
 

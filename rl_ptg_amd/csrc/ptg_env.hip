@@ -708,18 +708,17 @@ __global__ void k_build_fast(const DevParams P, const Rec* __restrict__ in, RecF
 // Dedicated float32 kernels for the common case: 13-hour look-ahead, no info rows, and NO env terminating inside the launch
 // (the host tracks the common step count of a synchronised batch and routes the one step per episode that terminates --
 // and everything unusual -- through the generic kernels above).  Same arithmetic as env_step<float, FAST>, laid out for a
-// machine that runs ONE wave per SIMD at N = 65 536 (1024 waves on 1024 SIMDs), where nothing hides latency but the order
-// of the instruction stream:
+// machine that runs few waves per SIMD at N = 65 536, where little hides latency but the order of the instruction stream:
 //   * few scalars: HotParams carries only what every step needs; ladder thresholds, table meta data and the _get_index
 //     lookup sit in LDS;
-//   * every address is (uniform base) + (32-bit lane byte offset): SGPR-base global_load / global_store, no 64-bit VALU math;
-//   * the integer state machine is branch-free (select chains in the reference's if / elif priority order); only two
-//     wave-uniform branches remain (some lane changes state; some lane switches partial <-> full load);
-//   * front(): issues ALL loads of a step in one burst (market features merged into dwordx4, prices, record gather);
-//   * k_rollout_hot is software-pipelined: the loads of step t+1 are issued BEFORE the 37 stores of step t, because vmcnt
-//     retires loads and stores in issue order -- a load issued behind the stores waits for their write acknowledgements.
-// Measured and rejected on MI355X: a "broadcast" form that stores the 28 features a synchronised wave shares
-// as 7 dwordx4 (its uniformity tests cost more than the 21 stores it saves), and 32 / 16 envs per wave for more waves per SIMD.
+//   * every address is (uniform base) + (32-bit lane byte offset): no per-feature 64-bit address registers;
+//   * the integer state machine is branch-free (select chains in the reference's if / elif priority order); only
+//     wave-uniform branches remain (some lane draws noise; some lane switches partial <-> full load);
+//   * k_step_hot (one vector step per launch) issues ALL loads of the step in one burst, then the stores;
+//   * k_rollout_pc (T fused steps) splits the step between producer waves (state machine + a 2-byte key gather: the only
+//     loop-carried chain) and consumer waves (record gather, reward, stores), see below.
+// Measured and rejected on MI355X: a single-role software-pipelined rollout kernel (2.0 us per step against
+// 1.55), a "broadcast" form that stores the 28 features a synchronised wave shares as 7 dwordx4, 32 / 16 envs per wave.
 template <typename T>
 __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) { return *(const T*)((const char*)base + byte_off); }
 // Output rows (observations, rewards, done flags) are written once and never read back by these kernels: non-temporal
@@ -1013,77 +1012,6 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
     }
 }
 
-// T fused steps, no env terminates inside (host-guaranteed): state in registers, small tables in LDS, actions fetched two
-// steps ahead, loads of step t+1 issued before the stores of step t
-template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT, bool PIPE>
-__global__ void __launch_bounds__(512, PIPE ? 1 : 3)      // plain order: <= 168 VGPRs, 3 waves per SIMD (4 would spill)
-k_rollout_hot(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
-              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    HotLds& L = *(HotLds*)s_dyn;
-    unsigned short* s_lut = (unsigned short*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
-    const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = e_raw < P.N;
-    const int e = live ? e_raw : P.N - 1;
-    const StA a = P.st_a[e]; const StB b = P.st_b[e];
-    int ri = 0, ni = 0; float rf = 0.f, nf = 0.f;
-    hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
-    if (T > 1) hot_fetch<ACTK>(actions, (size_t)P.N + e, ni, nf);
-    hot_stage_lds(P, L);
-    if (LDSLUT) {
-        const int words = (N_DEST * P.nT + 1) / 2;
-        const unsigned* src = (const unsigned*)lut16;
-        unsigned* dst = (unsigned*)s_lut;
-        for (int q = threadIdx.x; q < words; q += blockDim.x) dst[q] = src[q];
-    }
-    __syncthreads();
-    const unsigned short* lut = LDSLUT ? s_lut : nullptr;
-    HotRegs R;
-    R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
-    const double2 setc = P.setc[(R.flags >> 15) & 3];
-    const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
-    HotLoads Q;
-    hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, hot_decode<ACTK>(P, ri, rf, R.flags), e, k0 + 1, Q);   // prologue: front half of step 0
-    char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;
-    for (int t = 0; t < T; t++) {
-        const float r = hot_back(P, R, Q, setc, e, live);   // needs the record of step t
-        const int s_out = R.flags & 7;
-        if (PIPE) {                                         // one wave per SIMD: order the stream by hand
-            HotLoads Qn;
-            if (t + 1 < T) {                                // front half of step t+1 BEFORE the stores of step t
-                const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
-                if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
-                hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, k0 + t + 2, Qn);
-            }
-            if (live) {
-                hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
-                st_off<float>(rew_t, (unsigned)e * 4u, r);
-                st_off<uint8_t>(done_t, (unsigned)e, 0);
-            }
-            Q = Qn;
-        } else {                                            // large batches: several waves per SIMD hide latency; fewer registers
-            if (live) {
-                hot_store_obs<FM, MOD>(HotRow<FM>((float*)obs_t, P, e), Q, s_out);
-                st_off<float>(rew_t, (unsigned)e * 4u, r);
-                st_off<uint8_t>(done_t, (unsigned)e, 0);
-            }
-            if (t + 1 < T) {
-                const int act = hot_decode<ACTK>(P, ni, nf, R.flags);
-                if (t + 2 < T) hot_fetch<ACTK>(actions, (size_t)(t + 2) * P.N + e, ni, nf);
-                hot_front<MOD, NOISE>(P, L, lut, LDSLUT, R, act, e, k0 + t + 2, Q);
-            }
-        }
-        obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
-    }
-    if (live) {
-        StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
-        StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
-        P.st_a[e] = na; P.st_b[e] = nb;
-    }
-}
-
-
 // Producer / consumer form of the fused rollout ("split gather").  Half of every workgroup's waves (producers) run ONLY the
 // integer state machine: its loop-carried dependence on memory is the temperature key of the window just entered, so the
 // producers gather 2 bytes per env and step (rkey[], the keys of all window records as one uint16 array) and hand
@@ -1148,10 +1076,11 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     {
         const int sh_np = __ffs(NP) - 1, total = T << sh_np;
         const int e_wg = e_base + blockIdx.x * NP;
+        bool bad_any = false;           // flagged once after the loops: a ballot inside would keep them from unrolling
         auto code_of = [&](int ri, float rf) -> int {
             if (ACTK == PTG_ACT_F32) return decode_continuous(rf, 7);
             const bool bad = (ri < -5) | (ri > 4);
-            if (__ballot(bad)) { if (bad) atomicOr(P.err, 1); }
+            bad_any |= bad;
             return bad ? 7 : (ri < 0 ? ri + 5 : ri);
         };
         if (FULL && vec_rows) {          // four envs per lane: one dwordx4 (two for int64 actions) per quad, one packed LDS word
@@ -1184,6 +1113,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
                 s_act[idx] = (unsigned char)code_of(ri, rf);
             }
         }
+        if (__ballot(bad_any)) { if (bad_any) atomicOr(P.err, 1); }
     }
     hot_stage_lds(P, L);
     if (LDSLUT) {
@@ -1598,26 +1528,39 @@ void launch_step_hot(const ptg_env* h, hipStream_t st, const void* actions, int 
     else hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
 }
 
+// Launch geometry of the fused hot rollout.  One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many
+// steps as its LDS action stage holds; larger batches / longer rollouts run as consecutive launches over env slices and
+// step segments.
+struct PcPlan { int chunk, block, t_cap; bool lds_lut; size_t fixed, lut_bytes, lds_max; };
+
+PcPlan pc_plan(const ptg_env* h)
+{
+    PcPlan pl;
+    pl.chunk = getenv("PTG_PC_CHUNK") ? atoi(getenv("PTG_PC_CHUNK")) : 65536;
+    pl.chunk = std::max(256, pl.chunk / 256 * 256);
+    pl.fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);
+    pl.lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
+    pl.lds_max = 160 * 1024 - 512;
+    pl.block = 128;                                         // half producers, half consumers; >= 256 workgroups when possible
+    while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block) >= 256) pl.block *= 2;     // block/2 envs per workgroup
+    if (getenv("PTG_BLOCK")) pl.block = atoi(getenv("PTG_BLOCK"));
+    const int np = pl.block / 2;
+    // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
+    pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !getenv("PTG_NO_LDS_LUT");
+    const size_t avail = pl.lds_max - pl.fixed - (pl.lds_lut ? pl.lut_bytes : 0) - 64;
+    pl.t_cap = (int)std::min<size_t>(512, avail / np);
+    return pl;
+}
+
 template <bool FM, bool MOD, int NOISE>
-void launch_rollout_pc(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
+void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
-    // One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many steps as its LDS action stage holds;
-    // larger batches / longer rollouts run as consecutive launches over env slices and step segments.
-    int chunk = getenv("PTG_PC_CHUNK") ? atoi(getenv("PTG_PC_CHUNK")) : 65536;
-    chunk = std::max(256, chunk / 256 * 256);
+    const PcPlan pl = pc_plan(h);
+    const int chunk = pl.chunk, bs_all = pl.block, np = pl.block / 2, t_cap = pl.t_cap;
+    const bool ll = pl.lds_lut;
     const size_t asz = kind == PTG_ACT_I64 ? 8 : 4;
-    const size_t fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);
-    const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
-    const size_t lds_max = 160 * 1024 - 512;
-    int bs_all = 128;                                       // half producers, half consumers; >= 256 workgroups when possible
-    while (bs_all < 512 && (long long)grid_for(std::min(chunk, h->n), bs_all) >= 256) bs_all *= 2;     // bs/2 envs per workgroup
-    if (getenv("PTG_BLOCK")) bs_all = atoi(getenv("PTG_BLOCK"));
-    const int np = bs_all / 2;
-    // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
-    const bool ll = h->d_lut16 && fixed + lut_bytes + (size_t)64 * np + 64 <= lds_max && !getenv("PTG_NO_LDS_LUT");
-    const size_t avail = lds_max - fixed - (ll ? lut_bytes : 0) - 64;
-    const int t_cap = (int)std::min<size_t>(512, avail / np);
+    const size_t fixed = pl.fixed, lut_bytes = pl.lut_bytes, lds_max = pl.lds_max;
     for (int ts = 0; ts < T; ts += t_cap) {
         const int tn = std::min(t_cap, T - ts);
         const char* a_s = (const char*)actions + (size_t)ts * h->n * asz;
@@ -1645,29 +1588,6 @@ void launch_rollout_pc(const ptg_env* h, hipStream_t st, const void* actions, in
 #undef PTG_PC2
         }
     }
-}
-
-template <bool FM, bool MOD, int NOISE>
-void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
-{
-    if (getenv("PTG_USE_PC")) { launch_rollout_pc<FM, MOD, NOISE>(h, st, actions, kind, T, obs, rew, done); return; }   // experimental, same speed
-    const HotParams hp = make_hot_params(h);
-    int bs = 64;                                            // one lane per env; >= 256 workgroups when the batch allows, <= 512 threads
-    while (bs < 512 && (long long)grid_for(h->n, bs * 2) >= 256) bs *= 2;
-    if (getenv("PTG_BLOCK")) bs = atoi(getenv("PTG_BLOCK"));
-    const dim3 grid(grid_for(h->n, bs)), block(bs);
-    const size_t l_bytes = 16 * ((sizeof(HotLds) + 15) / 16);
-    const size_t lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
-    const bool ll = h->d_lut16 && l_bytes + lut_bytes <= 64000 && !getenv("PTG_NO_LDS_LUT");
-    const size_t sh = l_bytes + (ll ? lut_bytes : 0);
-    // one wave per SIMD (N <= 65 536 per GPU): software-pipelined stream; larger batches: plain order, fewer registers
-    const bool pipe = getenv("PTG_PIPE") ? atoi(getenv("PTG_PIPE")) != 0 : (h->n <= 65536);
-#define PTG_RH(ACTK, LL) do { if (pipe) hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL, true>), grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16); \
-                              else hipLaunchKernelGGL((k_rollout_hot<FM, MOD, NOISE, ACTK, LL, false>), grid, block, sh, st, hp, actions, h->sync_k, T, obs, rew, done, h->d_lut16); } while (0)
-    if (kind == PTG_ACT_F32) { if (ll) PTG_RH(PTG_ACT_F32, true); else PTG_RH(PTG_ACT_F32, false); }
-    else if (kind == PTG_ACT_I64) { if (ll) PTG_RH(PTG_ACT_I64, true); else PTG_RH(PTG_ACT_I64, false); }
-    else { if (ll) PTG_RH(PTG_ACT_I32, true); else PTG_RH(PTG_ACT_I32, false); }
-#undef PTG_RH
 }
 
 #define PTG_HOT_DISPATCH(FN, ...)                                                                       \
@@ -2061,7 +1981,7 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
         if (hot_eligible(h) && h->sync_k != k_term) {
             cnt = std::min(n_steps - t0, k_term - h->sync_k);
             PTG_HOT_DISPATCH(launch_rollout_hot, h, st, a_t, action_kind, cnt, (float*)o_t, (float*)r_t, d_t);
-            rc = launch_check(h, "k_rollout_hot");
+            rc = launch_check(h, "k_rollout_pc");
             h->sync_k += cnt;
         } else if (h->sync_k >= 0) {                            // the terminating step of a synchronised batch
             cnt = 1;
@@ -2075,6 +1995,26 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
         t0 += cnt;
     }
     return 0;
+}
+
+int ptg_rollout_launches(ptg_env* h, int n_steps)
+{
+    if (!h || n_steps < 1) return PTG_E_INVALID;
+    const int k_term = h->cfg.eps_sim_steps - 6;
+    int k = h->sync_k, t0 = 0, launches = 0;
+    while (t0 < n_steps) {                                  // mirrors the segment loop of ptg_rollout
+        if (hot_eligible(h) && k >= 0 && k != k_term) {
+            const PcPlan pl = pc_plan(h);
+            const int cnt = std::min(n_steps - t0, k_term - k);
+            launches += ((cnt + pl.t_cap - 1) / pl.t_cap) * ((h->n + pl.chunk - 1) / pl.chunk);
+            k += cnt; t0 += cnt;
+        } else if (k >= 0) {
+            launches += 1; k = (k == k_term) ? 0 : k + 1; t0 += 1;
+        } else {
+            launches += n_steps - t0; t0 = n_steps;
+        }
+    }
+    return launches;
 }
 
 int ptg_sync(ptg_env* h, void* stream)
@@ -2192,17 +2132,21 @@ int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_hos
     HIP_TRY(h, hipMemcpy(&total, h->P.fin_count, sizeof(int), hipMemcpyDeviceToHost));
     const int have = std::min(total, h->P.fin_cap);
     const int n = std::min(have, cap);
-    // entries [total - have, total) are live (ring); hand out the oldest n of them
-    std::vector<double> r(h->P.fin_cap); std::vector<int> l(h->P.fin_cap), id(h->P.fin_cap);
+    // entries [total - have, total) are live (ring); hand out the oldest n of them: at most two contiguous pieces
     if (n > 0) {
-        HIP_TRY(h, hipMemcpy(r.data(), h->P.fin_ret, sizeof(double) * h->P.fin_cap, hipMemcpyDeviceToHost));
-        HIP_TRY(h, hipMemcpy(l.data(), h->P.fin_len, sizeof(int) * h->P.fin_cap, hipMemcpyDeviceToHost));
-        HIP_TRY(h, hipMemcpy(id.data(), h->P.fin_env, sizeof(int) * h->P.fin_cap, hipMemcpyDeviceToHost));
-        for (int q = 0; q < n; q++) {
-            const int slot = (total - have + q) % h->P.fin_cap;
-            if (returns_host) returns_host[q] = r[slot];
-            if (lengths_host) lengths_host[q] = l[slot];
-            if (env_ids_host) env_ids_host[q] = id[slot];
+        const int cap_r = h->P.fin_cap, s0 = (total - have) % cap_r;
+        const int n0 = std::min(n, cap_r - s0), n1 = n - n0;
+        if (returns_host) {
+            HIP_TRY(h, hipMemcpy(returns_host, h->P.fin_ret + s0, sizeof(double) * n0, hipMemcpyDeviceToHost));
+            if (n1) HIP_TRY(h, hipMemcpy(returns_host + n0, h->P.fin_ret, sizeof(double) * n1, hipMemcpyDeviceToHost));
+        }
+        if (lengths_host) {
+            HIP_TRY(h, hipMemcpy(lengths_host, h->P.fin_len + s0, sizeof(int) * n0, hipMemcpyDeviceToHost));
+            if (n1) HIP_TRY(h, hipMemcpy(lengths_host + n0, h->P.fin_len, sizeof(int) * n1, hipMemcpyDeviceToHost));
+        }
+        if (env_ids_host) {
+            HIP_TRY(h, hipMemcpy(env_ids_host, h->P.fin_env + s0, sizeof(int) * n0, hipMemcpyDeviceToHost));
+            if (n1) HIP_TRY(h, hipMemcpy(env_ids_host + n0, h->P.fin_env, sizeof(int) * n1, hipMemcpyDeviceToHost));
         }
     }
     HIP_TRY(h, hipMemset(h->P.fin_count, 0, sizeof(int)));

@@ -218,6 +218,13 @@ class HipEngine:
                                           C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
         return obs, rew, done
 
+    def rollout_launches(self, n_steps):
+        """Kernel launches a rollout of n_steps would issue from the envs' current position (per-launch timing)."""
+        k = self._L.ptg_rollout_launches(self._h, int(n_steps))
+        if k < 0:
+            self._chk(k)
+        return k
+
     def sync(self):
         self._chk(self._L.ptg_sync(self._h, self._stream()))
 

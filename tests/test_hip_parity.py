@@ -425,3 +425,76 @@ def test_differential_vs_oracle_other_step_sizes(sim_step, action_type, raw_modi
     # ladder coverage: every partial-load and full-load table was in use somewhere in the batch
     assert len(set(eng.get_state("partial_tid").tolist())) >= 3 and len(set(eng.get_state("full_tid").tolist())) >= 3
     eng.close(); ora.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("action_type", ["discrete", "continuous"])
+def test_fused_rollout_slices_segments_and_kept_actions(action_type):
+    """The fused rollout runs as env slices x step segments with the launch's actions staged in LDS as one-byte codes.
+    n = 1000 envs in 256-env slices (ragged last slice and workgroup), 700 steps (two segments of the 512-step stage), action
+    rows that hold "keep the previous action" codes (continuous: values >= 1 and NaN, :351-355): bit-identical to the
+    all-generic route and to per-step launches; the launch count reported by the library matches the geometry."""
+    import os
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=8, train_steps=400000, action_type=action_type)
+    n, K = 1000, 700
+    rng = np.random.default_rng(21)
+    if action_type == "discrete":
+        acts = rng.integers(-5, 5, (K, n)).astype(np.int64)          # python-style negative indices included (:347)
+    else:
+        acts = rng.uniform(-1.2, 1.3, (K, n)).astype(np.float32)
+        acts[rng.random((K, n)) < 0.05] = np.nan
+    res = {}
+    for route in ("generic", "sliced", "steps"):
+        env = {"generic": {"PTG_NO_HOT_KERNELS": "1"}, "sliced": {"PTG_PC_CHUNK": "256"}, "steps": {}}[route]
+        os.environ.update(env)
+        try:
+            eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="feature")
+            eng.set_episode_plan(spec.eps_ind, n, n)
+            eng.set_noise_rng(5)
+            eng.reset()
+            if route == "sliced":
+                assert eng.rollout_launches(K) == 2 * 4                  # ceil(700 / 512) segments x ceil(1000 / 256) slices
+            if route == "steps":
+                oo, rr = [], []
+                for t in range(K):
+                    o, r, d = eng.step(acts[t])
+                    eng.sync()
+                    oo.append(o.cpu().numpy().copy()); rr.append(r.cpu().numpy().copy())
+                out = (np.array(oo), np.array(rr))
+            else:
+                o, r, d = eng.rollout(acts)
+                eng.sync()
+                out = (o.cpu().numpy(), r.cpu().numpy())
+            res[route] = (out, {f: eng.get_state(f) for f in INT_FIELDS + ["noise_count", "cum_rew", "current_action"]})
+            eng.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    for route in ("sliced", "steps"):
+        assert np.array_equal(res[route][0][0], res["generic"][0][0]), route
+        assert np.array_equal(res[route][0][1], res["generic"][0][1]), route
+        for f, v in res["generic"][1].items():
+            assert np.array_equal(res[route][1][f], v), (route, f)
+
+
+@pytest.mark.gpu
+def test_fused_rollout_flags_invalid_discrete_action():
+    """An out-of-range discrete action inside a fused rollout raises PTG_E_ACTION at the next sync (IndexError in the
+    reference, :347) and leaves the env on its previous action."""
+    from rl_ptg_amd.engine import HipEngine, PtgError
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=8)
+    n, K = 300, 20
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="feature")
+    eng.set_episode_plan(spec.eps_ind, n, n)
+    eng.set_noise_rng(1)
+    eng.reset()
+    acts = np.full((K, n), 2, np.int32)
+    acts[7, 123] = 9
+    eng.rollout(acts)
+    with pytest.raises(PtgError):
+        eng.sync()
+    assert int(eng.get_state("current_action")[123]) == 2
+    eng.close()
