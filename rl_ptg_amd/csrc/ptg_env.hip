@@ -940,8 +940,35 @@ struct HotRow {                  // observation row addressing: uniform base + 3
     __device__ __forceinline__ void put_u(int q, float v) const { st_off<float>(base + (size_t)q * qbytes, boff, v); }
 };
 
-template <bool FM, bool MOD>
-__device__ __forceinline__ void hot_store_obs(const HotRow<FM>& row, const HotLoads& Q, int s)
+// Row-major observations ([N][F], the reference's layout): a lane's row is 140 B away from its neighbour's, so per-feature
+// stores would be 64 scattered 4-byte writes each.  Instead every wave transposes its 64 rows through a private LDS tile and
+// writes them back as ONE contiguous block of 64 * F floats with dwordx4 stores (64 * 140 B = 70 full 128-byte lines).
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <bool MOD>
+struct RowTile {
+    static constexpr int F = MOD ? 35 : 26;
+    static constexpr int N4 = 64 * F / 4;                  // float4 per wave block (560 / 416)
+    float* t;                                              // this wave's [64][F] tile
+    int lane;
+    __device__ __forceinline__ RowTile(float* tiles, int wave) : t(tiles + wave * 64 * F), lane(threadIdx.x & 63) {}
+    __device__ __forceinline__ void put(int q, float v) const { t[lane * F + q] = v; }
+    __device__ __forceinline__ void put_u(int q, float v) const { put(q, v); }
+    // rows = address of the wave's first row; all 64 lanes of the wave must be live
+    __device__ __forceinline__ void flush(float* rows) const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < (N4 + 63) / 64; j++) {
+            const int g = lane + 64 * j;
+            if (g < N4) __builtin_nontemporal_store(((const vf4*)t)[g], (vf4*)rows + g);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+template <bool MOD, class Sink>
+__device__ __forceinline__ void hot_store_obs(const Sink& row, const HotLoads& Q, int s)
 {
 #pragma unroll
     for (int q = 0; q < 13; q++) row.put(q, Q.fa[q]);
@@ -987,6 +1014,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
            uint8_t* __restrict__ done)
 {
     __shared__ HotLds L;
+    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * 64 * RowTile<MOD>::F];      // row-major: one tile per wave
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
@@ -1002,8 +1030,14 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
     HotLoads Q;
     hot_front<MOD, NOISE>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
     const float r = hot_back(P, R, Q, setc, e, live);
+    const bool wave_full = __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // e_raw of lane 0: the wave's first env
+    if (!FM && wave_full) {
+        const RowTile<MOD> tile(s_tile, threadIdx.x >> 6);
+        hot_store_obs<MOD>(tile, Q, R.flags & 7);
+        tile.flush(obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * RowTile<MOD>::F);
+    }
     if (live) {
-        hot_store_obs<FM, MOD>(HotRow<FM>(obs, P, e), Q, R.flags & 7);
+        if (FM || !wave_full) hot_store_obs<MOD>(HotRow<FM>(obs, P, e), Q, R.flags & 7);
         st_off<float>(rew, (unsigned)e * 4u, r);
         st_off<uint8_t>(done, (unsigned)e, 0);
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
@@ -1057,7 +1091,8 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     HotLds& L = *(HotLds*)s_dyn;
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
     const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256)
-    unsigned char* s_act = (unsigned char*)slot + 2 * sizeof(PcSlot);                    // [T][NP] decoded actions of the launch
+    float* s_tiles = (float*)((unsigned char*)slot + 2 * sizeof(PcSlot));               // row-major: one [64][F] tile per consumer wave
+    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)NP * RowTile<MOD>::F * 4);      // [T][NP] decoded actions of the launch
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
     const int lx = producer ? threadIdx.x : threadIdx.x - NP;
@@ -1066,6 +1101,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     // exact (a skipped-stores path makes it assume the worst and drain the queue every step)
     const bool live = FULL || e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
+    const bool wave_full = FULL || __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // all 64 envs of this wave exist
     const StA a = P.st_a[e]; const StB b = P.st_b[e];
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
@@ -1184,8 +1220,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
         R.cum += rw;
         rw -= changed ? setc.y : 0.0;                                            // :332
         if (P.track_changes) { if (changed && live) P.st_c[e].nchg += 1; }
-        if (live) {
-            const HotRow<FM> row((float*)obs_t, P, e);
+        auto emit = [&](const auto& row) {
 #pragma unroll
             for (int q = 0; q < 13; q++) row.put_u(q, M.fa[q]);
 #pragma unroll
@@ -1194,10 +1229,18 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
             row.put_u(o + 0, (float)((w >> 24) & 7u));
 #pragma unroll
             for (int q = 0; q < 6; q++) row.put_u(o + 1 + q, rec.feat[q]);
-            st_off<float>(rew_t, (unsigned)e * 4u, (float)rw);
-            st_off<uint8_t>(done_t, (unsigned)e, 0);
             row.put_u(o + 7, sc.x);
             row.put_u(o + 8, sc.y);
+        };
+        if (!FM && wave_full) {                             // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
+            const RowTile<MOD> tile(s_tiles, (int)(threadIdx.x >> 6) - (NP >> 6));
+            emit(tile);
+            tile.flush((float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * RowTile<MOD>::F);
+        }
+        if (live) {
+            if (FM || !wave_full) emit(HotRow<FM>((float*)obs_t, P, e));
+            st_off<float>(rew_t, (unsigned)e * 4u, (float)rw);
+            st_off<uint8_t>(done_t, (unsigned)e, 0);
         }
         obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
         if (reload) { M = Mn; hour_cur = hour_next; }
@@ -1538,13 +1581,14 @@ PcPlan pc_plan(const ptg_env* h)
     PcPlan pl;
     pl.chunk = getenv("PTG_PC_CHUNK") ? atoi(getenv("PTG_PC_CHUNK")) : 65536;
     pl.chunk = std::max(256, pl.chunk / 256 * 256);
-    pl.fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);
+    pl.fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);     // + the row-major tiles, below
     pl.lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
     pl.lds_max = 160 * 1024 - 512;
     pl.block = 128;                                         // half producers, half consumers; >= 256 workgroups when possible
     while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block) >= 256) pl.block *= 2;     // block/2 envs per workgroup
     if (getenv("PTG_BLOCK")) pl.block = atoi(getenv("PTG_BLOCK"));
     const int np = pl.block / 2;
+    if (!h->fm) pl.fixed += (size_t)np * h->F * 4;          // one [64][F] float tile per consumer wave
     // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
     pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !getenv("PTG_NO_LDS_LUT");
     const size_t avail = pl.lds_max - pl.fixed - (pl.lds_lut ? pl.lut_bytes : 0) - 64;

@@ -8,11 +8,11 @@ from collections import defaultdict
 
 tag = sys.argv[1]
 os.makedirs("profiles", exist_ok=True)
-ours = ("k_step", "k_rollout", "k_reset", "k_build", "k_fill", "k_init", "k_zero")
+ours = ("k_step", "k_rollout", "k_reset", "k_build", "k_fill", "k_init", "k_zero", "k_extract")
 
 
 def short(name):
-    for k in ("k_step_hot", "k_rollout_hot", "k_step", "k_rollout", "k_reset", "k_build_records", "k_build_argmin", "k_build_fast", "k_fill_noise", "k_init_state", "k_zero_noise_count"):
+    for k in ("k_step_hot", "k_rollout_pc", "k_extract_keys", "k_step", "k_rollout", "k_reset", "k_build_records", "k_build_argmin", "k_build_fast", "k_fill_noise", "k_init_state", "k_zero_noise_count"):
         if k in name:
             return k
     return name[:60]
@@ -44,10 +44,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 lines = [f"# rocprofv3 summary, {tag}", "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (defaults: 200 warm-up + 200 timed steps of both",
-         "paths: every k_rollout_hot dispatch is one 200-step launch, every k_step_hot dispatch one vector step; 1x MI355X, N = 65536 envs,",
+         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (defaults: 400 warm-up + 400 timed steps of both",
+         "paths: every k_rollout_pc dispatch is one 400-step launch, every k_step_hot dispatch one vector step; 1x MI355X, N = 65536 envs,",
          "BS1/OP1, float32 feature-major obs, in-kernel RNG).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of",
-         "`bench.py --steps 50 --warmup 5 --launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads);",
+         "`bench.py --steps 100 --warmup 10 --launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads);",
          "counter unit KiB.", "",
          "| kernel | dispatches | avg us | min us | max us | VGPR | SGPR | LDS B | block | grid |", "|---|---|---|---|---|---|---|---|---|---|"]
 for k in sorted(trace, key=lambda x: -sum(trace[x])):
@@ -57,17 +57,21 @@ for k in sorted(trace, key=lambda x: -sum(trace[x])):
     lines.append(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {min(d) / 1e3:.2f} | {max(d) / 1e3:.2f} | {m['VGPR_Count']} | {m['SGPR_Count']} | {m['LDS_Block_Size']} | {m['Workgroup_Size_X']} | {m['Grid_Size_X']} |")
 traffic = {}
 lines += ["", "| kernel | FETCH_SIZE KiB/launch (raw) | read bytes/launch (x2 corrected) | WRITE_SIZE KiB/launch | HBM bytes/launch |", "|---|---|---|---|---|"]
-for k in ("k_step_hot", "k_rollout_hot"):
+for k in ("k_step_hot", "k_rollout_pc"):
     if k in pmc:
         fs = pmc[k].get("FETCH_SIZE", [])
         ws = pmc[k].get("WRITE_SIZE", [])
-        # rollout: the 5-step warm-up launch and the 50-step launch differ; use the largest (the timed launch)
+        # rollout: the 10-step warm-up launch and the 100-step launch differ; use the largest (the timed launch)
         f = max(fs) if fs else None
         w_ = max(ws) if ws else None
         tot = (2 * f * 1024 if f else 0) + (w_ * 1024 if w_ else 0)
         lines.append(f"| {k} | {f} | {2 * f * 1024 if f else None} | {w_} | {tot} |")
         traffic[("step" if k == "k_step_hot" else "rollout") + "_bytes_per_launch"] = tot
-        traffic[("step" if k == "k_step_hot" else "rollout") + "_pmc_launch_steps"] = 1 if k == "k_step_hot" else 50
+        traffic[("step" if k == "k_step_hot" else "rollout") + "_pmc_launch_steps"] = 1 if k == "k_step_hot" else 100
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+if "rollout_bytes_per_launch" in traffic and "step_bytes_per_launch" in traffic:      # what bench.py reports as roofline.traffic
+    json.dump({"source": f"profiles/{tag}_summary.md", "step_bytes_per_launch": traffic["step_bytes_per_launch"],
+               "rollout_bytes_per_step": traffic["rollout_bytes_per_launch"] / traffic["rollout_pmc_launch_steps"]},
+              open("profiles/traffic_latest.json", "w"), indent=1)
 print("\n".join(lines))
