@@ -126,6 +126,7 @@ def main():
     def measure(path, launch):
         """W warm-up steps, then exactly K timed steps of `path`; returns (wall seconds, device ms, finished episodes)."""
         nonlocal F
+        torch.cuda.empty_cache()                              # each leg starts from a fresh allocator state (no recycled multi-GB blocks)
         eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
         F = eng.obs_dim
         eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
