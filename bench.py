@@ -72,7 +72,7 @@ def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--path", choices=["step", "rollout"], default="rollout",
@@ -222,7 +222,7 @@ def main():
             return tj["rollout_bytes_per_step"] * K / n_launch_of[path] if "rollout_bytes_per_step" in tj else None
         roof["traffic"] = traffic(args.path)
         path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
-                     "rollout": f"ptg_rollout, K steps fused ({n_launch_of['rollout']} kernel launch(es): <= 65536 envs x <= ~445 steps each)"}
+                     "rollout": f"ptg_rollout, K steps fused ({n_launch_of['rollout']} kernel launch(es): <= 65536 envs x <= ~400 steps each)"}
         line = {
             "metric": "env-steps/sec at N=65536 envs; achieved HBM GB/s vs roofline",
             "value": n_total * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -177,7 +177,9 @@ int ptg_get_state(ptg_env* env, int field, void* out_host);
 int ptg_set_state(ptg_env* env, int field, const void* in_host);
 
 /* Episodes finished since the last call (Monitor's info["episode"]: r = sum of returned rewards, l = steps),
- * compacted on the device with a wave ballot prefix.  Returns up to cap entries and clears the list. */
+ * compacted on the device with a wave ballot prefix.  Returns up to cap entries and clears the list.  The list is a ring
+ * of max(2 * n_envs, 1024) entries: when more episodes finish between two calls the oldest are dropped.  Synchronises the
+ * device only if a launch that can finish episodes (a generic / terminating step) ran since the last call. */
 int ptg_finished_episodes(ptg_env* env, double* returns_host, int32_t* lengths_host, int32_t* env_ids_host,
                           int cap, int* count);
 

@@ -1318,6 +1318,7 @@ struct ptg_env {
     std::vector<float> pool32_host;
     int* d_ladder = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
+    bool fin_maybe = false;      // a generic step ran since the last ptg_finished_episodes: only those can finish episodes
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
     int* d_eps_ind = nullptr;
@@ -1947,6 +1948,7 @@ static int launch_step_generic(ptg_env* h, hipStream_t st, const void* actions_d
 {
     const dim3 grid(grid_for(h->n, 256)), block(256);
     const bool f64 = h->cfg.out_dtype == PTG_OUT_F64;
+    h->fin_maybe = true;
 #define PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, PAC)                                                                     \
     hipLaunchKernelGGL((k_step<OUT, FAST, INFO, FM, PAC>), grid, block, 0, st, h->P, actions_dev, action_kind, (OUT*)obs_dev, \
                        (OUT*)rew_dev, done_dev, (OUT*)final_obs_dev, info_dev)
@@ -2170,8 +2172,10 @@ int ptg_set_state(ptg_env* h, int field, const void* in_host)
 int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_host, int32_t* env_ids_host, int cap, int* count)
 {
     if (!h || !count || cap < 0) return set_err(h, PTG_E_INVALID, "bad argument");
+    if (!h->fin_maybe) { *count = 0; return 0; }          // only hot launches since the last query: nothing can have finished
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
+    h->fin_maybe = false;
     int total = 0;
     HIP_TRY(h, hipMemcpy(&total, h->P.fin_count, sizeof(int), hipMemcpyDeviceToHost));
     const int have = std::min(total, h->P.fin_cap);

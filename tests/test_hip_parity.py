@@ -498,3 +498,41 @@ def test_fused_rollout_flags_invalid_discrete_action():
         eng.sync()
     assert int(eng.get_state("current_action")[123]) == 2
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["row", "feature"])
+@pytest.mark.parametrize("variant", ["default", "no_lds_lut", "block128"])
+def test_hot_kernels_raw_features_and_launch_variants(layout, variant):
+    """'raw' observations (26 columns: the row-major tile has an even stride) and the launch variants of the fused rollout
+    (lookup table left in global memory, 64-env workgroups) against the generic kernels, bit for bit."""
+    import os
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=3, operation="OP2", eps_len_d=8, raw_modified="raw", train_steps=400000)
+    n, K = 640, 120
+    acts = np.random.default_rng(17).integers(0, 5, (K, n)).astype(np.int32)
+    env = {"default": {}, "no_lds_lut": {"PTG_NO_LDS_LUT": "1"}, "block128": {"PTG_BLOCK": "128"}}[variant]
+    out = {}
+    for route in ("generic", "hot"):
+        e2 = dict(env) if route == "hot" else {"PTG_NO_HOT_KERNELS": "1"}
+        os.environ.update(e2)
+        try:
+            eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout=layout)
+            assert eng.obs_dim == 26
+            eng.set_episode_plan(spec.eps_ind, n, n)
+            eng.set_noise_rng(11)
+            eng.reset()
+            o, r, d = eng.rollout(acts[:100])
+            rest = [eng.step(acts[t]) for t in range(100, K)]
+            eng.sync()
+            out[route] = (o.cpu().numpy(), r.cpu().numpy(), np.array([x[0].cpu().numpy() for x in rest]),
+                          {f: eng.get_state(f) for f in INT_FIELDS + ["cum_rew", "noise_count"]})
+            eng.close()
+        finally:
+            for k in e2:
+                os.environ.pop(k, None)
+    assert np.array_equal(out["hot"][0], out["generic"][0]) and np.array_equal(out["hot"][1], out["generic"][1])
+    assert np.array_equal(out["hot"][2], out["generic"][2])
+    for f, v in out["generic"][3].items():
+        assert np.array_equal(out["hot"][3][f], v), f

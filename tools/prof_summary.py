@@ -44,8 +44,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 lines = [f"# rocprofv3 summary, {tag}", "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (defaults: 400 warm-up + 400 timed steps of both",
-         "paths: every k_rollout_pc dispatch is one 400-step launch, every k_step_hot dispatch one vector step; 1x MI355X, N = 65536 envs,",
+         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (defaults: 400 warm-up + 2000 timed steps of both",
+         "paths: the k_rollout_pc dispatches are the 400-step warm-up launch and the timed rollout's 401 + 401 + 401 + 401 + 396-step launches",
+         "(400 steps per launch on average, as in bench.py's avg_launch_us); every k_step_hot dispatch is one vector step; 1x MI355X, N = 65536 envs,",
          "BS1/OP1, float32 feature-major obs, in-kernel RNG).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of",
          "`bench.py --steps 100 --warmup 10 --launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads);",
          "counter unit KiB.", "",
