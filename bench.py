@@ -154,6 +154,8 @@ def main():
 
         run(0, W)
         eng.sync()
+        if world > 1:                                         # untimed: the collective of the timed region has run once
+            ptg_dist.all_gather_finished(np.zeros(0), np.zeros(0, np.int64), device=coll_device)
         graph = None
         if path == "step" and launch == "graph":                # K ptg_step launches captured once, replayed as one hipGraph
             side = torch.cuda.Stream(device=device)

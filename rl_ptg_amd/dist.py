@@ -33,8 +33,8 @@ def mixed_scenario_assignment(n_total, world_size, rank, n_sets):
 def all_gather_finished(returns, lengths, device=None, group=None):
     """All-gather variable-length finished-episode lists over the process group.
 
-    Returns (returns_all, lengths_all) ordered by rank.  Two collectives: the counts, then the padded payload
-    (float64 return + length packed as [max_count, 2]).  With no initialised process group this is the identity."""
+    Returns (returns_all, lengths_all) ordered by rank.  One collective for the counts and, only when some rank has
+    entries, one for the padded payload (float64 return + length packed as [max_count, 2]).  With no initialised process group this is the identity."""
     import torch
     import torch.distributed as dist
     returns = np.asarray(returns, dtype=np.float64)
@@ -43,20 +43,28 @@ def all_gather_finished(returns, lengths, device=None, group=None):
         return returns, lengths
     world = dist.get_world_size(group)
     dev = torch.device("cpu") if device is None else device
-    cnt = torch.tensor([len(returns)], dtype=torch.int64, device=dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    counts = [int(c.item()) for c in cnts]
-    m = max(max(counts), 1)
-    payload = torch.zeros((m, 2), dtype=torch.float64, device=dev)
+
+    def gather_rows(x):                       # x [m, c] on every rank -> [world, m, c] on the host, one collective + one copy
+        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=dev)
+        try:
+            dist.all_gather_into_tensor(out.view(-1), x.reshape(-1), group=group)
+        except (RuntimeError, NotImplementedError, AttributeError):       # backend without the flat form
+            parts = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(parts, x, group=group)
+            out = torch.stack(parts)
+        return out.cpu().numpy()
+
+    counts = gather_rows(torch.tensor([[len(returns)]], dtype=torch.int64, device=dev)).reshape(world).tolist()
+    m = max(counts)
+    if m == 0:                                # the common case between episode ends: one small collective in total
+        return returns[:0], lengths[:0]
+    payload = torch.zeros((m, 2), dtype=torch.float64)
     if len(returns):
-        payload[:len(returns), 0] = torch.from_numpy(returns).to(dev)
-        payload[:len(returns), 1] = torch.from_numpy(lengths.astype(np.float64)).to(dev)
-    bufs = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(bufs, payload, group=group)
+        payload[:len(returns), 0] = torch.from_numpy(returns)
+        payload[:len(returns), 1] = torch.from_numpy(lengths.astype(np.float64))
+    bufs = gather_rows(payload.to(dev))
     r_all, l_all = [], []
     for c, b in zip(counts, bufs):
-        b = b.cpu().numpy()
         r_all.append(b[:c, 0])
         l_all.append(b[:c, 1].astype(np.int64))
     return np.concatenate(r_all), np.concatenate(l_all)
