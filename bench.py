@@ -83,8 +83,8 @@ def main():
     ap.add_argument("--scenario", type=int, default=1)
     ap.add_argument("--operation", default="OP1")
     ap.add_argument("--out-dtype", choices=["float32", "float64"], default="float32")
-    ap.add_argument("--obs-layout", choices=["row", "feature"], default="feature",
-                    help="observation matrix layout: feature-major [F][N] (coalesced SoA stores) or row-major [N][F]")
+    ap.add_argument("--obs-layout", choices=["row", "feature", "sb3_flat"], default="feature",
+                    help="observation matrix layout: feature-major [F][N] (coalesced SoA stores), row-major [N][F], or SB3's flattened [N][F+5] rows")
     ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
     ap.add_argument("--noise", choices=["rng", "tape"], default="rng", help="in-kernel counter RNG or a device-filled tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -52,8 +52,12 @@ enum { PTG_ACT_I32 = 0, PTG_ACT_F32 = 1, PTG_ACT_I64 = 2 };   /* element type of
 enum { PTG_OUT_F32 = 0, PTG_OUT_F64 = 1 };                    /* element type of obs / reward buffers */
 /* Observation matrix layout.  ROW_MAJOR [N][F] is what DummyVecEnv hands to SB3 (one row per env).  FEATURE_MAJOR [F][N]
  * is the struct-of-arrays form the kernels write with fully coalesced stores (a wave writes 64 consecutive envs of one
- * feature); its transpose view is the same [N][F] matrix, e.g. torch: obs.t(). Rollouts: [T][N][F] resp. [T][F][N]. */
-enum { PTG_OBS_ROW_MAJOR = 0, PTG_OBS_FEATURE_MAJOR = 1 };
+ * feature); its transpose view is the same [N][F] matrix, e.g. torch: obs.t(). Rollouts: [T][N][F] resp. [T][F][N].
+ * SB3_FLAT [N][F + 5] is the row SB3's CombinedExtractor builds from the Dict observation (the reference's policies are
+ * "MultiInputPolicy"): sub-spaces concatenated in sorted key order, the Discrete(6) METH_STATUS one-hot encoded -- 40
+ * columns for 'mod', 31 for 'raw' at price_ahead 13; ptg_obs_dim() reports the width.  Replaces: obs_as_tensor +
+ * preprocess_obs + CombinedExtractor.forward on the caller's side. */
+enum { PTG_OBS_ROW_MAJOR = 0, PTG_OBS_FEATURE_MAJOR = 1, PTG_OBS_SB3_FLAT = 2 };
 
 /* Constants of the env: the flat kwargs of Preprocessing.dict_env_kwargs (src/rl_utils.py:345-365), same names.
  * Replaces: the attribute set PTGEnv.__init__ copies from dict_input (env/ptg_gym_env.py:40). */
@@ -77,7 +81,7 @@ typedef struct ptg_config {
     double state_change_penalty;        /* :332 */
     double t_cat_initial;               /* 16 in the reference (:117) */
     int32_t out_dtype;                  /* PTG_OUT_F32 | PTG_OUT_F64 */
-    int32_t obs_layout;                 /* PTG_OBS_ROW_MAJOR | PTG_OBS_FEATURE_MAJOR */
+    int32_t obs_layout;                 /* PTG_OBS_ROW_MAJOR | PTG_OBS_FEATURE_MAJOR | PTG_OBS_SB3_FLAT */
 } ptg_config;
 
 /* The 17 process tables (src/rl_utils.py:46-67): row-major [rows][7] = t, T_cat, n_h2, n_ch4, n_h2_res, m_h2o, P_el */

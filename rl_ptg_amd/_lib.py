@@ -14,7 +14,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 N_TABLES, N_INFO = 17, 24
 ACT_I32, ACT_F32, ACT_I64 = 0, 1, 2
 OUT_F32, OUT_F64 = 0, 1
-OBS_ROW_MAJOR, OBS_FEATURE_MAJOR = 0, 1
+OBS_ROW_MAJOR, OBS_FEATURE_MAJOR, OBS_SB3_FLAT = 0, 1, 2
 
 _D1 = ["noise"]
 _I1 = ["eps_len_d", "sim_step", "time_step_op", "price_ahead"]

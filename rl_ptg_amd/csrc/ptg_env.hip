@@ -102,6 +102,7 @@ struct DevParams {
     StA* st_a; StB* st_b; StC* st_c;
     // finished-episode list
     double* fin_ret; int* fin_len; int* fin_env; int* fin_count; int fin_cap;
+    const int* cmap; int q_stat;          // SB3_FLAT layout: canonical column -> flat column; canonical index of METH_STATUS (else cmap = null)
     int* err;
 };
 
@@ -366,11 +367,25 @@ __device__ __forceinline__ int step_ints(const DevParams& P, const int2* tabmeta
 // lanes of a wave are consecutive envs, so every feature store is one contiguous 256-B (f32) / 512-B (f64) segment.
 template <typename OUT, bool FM>
 struct ObsRow {
-    OUT* p; size_t stride;
+    OUT* p; size_t stride; const int* cmap; int q_stat;
     __device__ __forceinline__ ObsRow(OUT* base, const DevParams& P, int e)
-        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.N : 1) {}
-    __device__ __forceinline__ void put(int q, OUT v) const { p[(size_t)q * stride] = v; }
-    __device__ __forceinline__ OUT get(int q) const { return p[(size_t)q * stride]; }
+        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.N : 1), cmap(FM ? nullptr : P.cmap), q_stat(P.q_stat) {}
+    // q = canonical column (the reference's observation order); SB3_FLAT rows hold the columns in sorted-key order with
+    // METH_STATUS one-hot over 6 classes
+    __device__ __forceinline__ void put(int q, OUT v) const
+    {
+        if (!FM && cmap) {
+            const int c = cmap[q];
+            if (q == q_stat) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) p[c + j] = (OUT)(((int)v == j) ? 1 : 0);
+            } else p[c] = v;
+        } else p[(size_t)q * stride] = v;
+    }
+    __device__ __forceinline__ void copy_row_from(const ObsRow& src, int F) const     // same layout on both sides
+    {
+        for (int q = 0; q < F; q++) p[(size_t)q * stride] = src.p[(size_t)q * src.stride];
+    }
     __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
 };
 
@@ -619,7 +634,7 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
             if (term) {
                 if (final_obs) {
                     const ObsRow<OUT, FM> frow(final_obs, P, e);
-                    for (int q = 0; q < P.F; q++) frow.put(q, row.get(q));
+                    frow.copy_row_from(row, P.F);
                 }
                 ret = R.b.cum;
                 if (P.track_changes) { need_c(P, e, R); ret -= (double)R.c.nchg * P.setc[(R.a.flags >> 15) & 3].y; }
@@ -739,7 +754,7 @@ enum { LAD_T1_START_P_F = 0, LAD_T2_START_F_P, LAD_T_P_F, LAD_T_F_P, LAD_T1_P_F_
        LAD_T4_F_P_F, LAD_T45_F_P_F, LAD_T5_F_P_F, LAD_I_FULL, LAD_J_FULL, LAD_N };
 
 struct HotParams {
-    int N, S, sim_step, eps_sim_steps, F, nT, tape_len, track_changes;
+    int N, S, sim_step, eps_sim_steps, F, nT, tape_len, track_changes, flat;
     int key_cold_max, key_hot_min, key_standby_max, n_hours, n_days, hstride, dstride;
     unsigned off_featB, off_gasn, off_euan, off_sc;   // element offsets into pool32 (featA at 0; sin/cos pairs at off_sc)
     unsigned off_gas, off_eua;                        // element offsets into pool64 (el at 0)
@@ -930,15 +945,48 @@ __device__ __forceinline__ float hot_back(const HotParams& P, HotRegs& R, const 
     return (float)rew;
 }
 
-template <bool FM>
+template <bool FM, bool MOD = true>
 struct HotRow {                  // observation row addressing: uniform base + 32-bit lane byte offset (feature q adds q * qbytes)
-    char* base; unsigned boff; unsigned qbytes;
+    char* base; unsigned boff; unsigned qbytes; bool flat;
     __device__ __forceinline__ HotRow(float* b, const HotParams& P, int e)
-        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u) {}
-    __device__ __forceinline__ void put(int q, float v) const { st_off<float>(base, boff + (unsigned)q * qbytes, v); }
+        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u), flat(!FM && P.flat) {}
+    __device__ __forceinline__ void put(int q, float v) const;
     // same address as (uniform pointer advanced by SALU) + (the one lane offset): no per-feature offset registers
-    __device__ __forceinline__ void put_u(int q, float v) const { st_off<float>(base + (size_t)q * qbytes, boff, v); }
+    __device__ __forceinline__ void put_u(int q, float v) const;
 };
+
+// SB3_FLAT layout (price_ahead = 13): canonical column q -> column of the flat row, sub-spaces in sorted key order
+// ('mod': CH4_syn, Elec_Heating, H2O_DE, H2_in, H2_res, METH_STATUS x6, Part_Full x13, Pot_Reward x13, T_CAT, cos, sin;
+//  'raw': CH4_syn, EUA_Price x2, Elec_Heating, Elec_Price x13, Gas_Price x2, H2O_DE, H2_in, H2_res, METH_STATUS x6, T_CAT, cos, sin).
+// ptg_create checks this table against the general host-built map.
+template <bool MOD>
+__host__ __device__ constexpr int flat_col(int q)
+{
+    if (MOD) {
+        return q < 13 ? 24 + q : q < 26 ? 11 + (q - 13)
+             : q == 26 ? 5 : q == 27 ? 37 : q == 28 ? 3 : q == 29 ? 0 : q == 30 ? 4 : q == 31 ? 2 : q == 32 ? 1 : q == 33 ? 39 : 38;
+    }
+    return q < 13 ? 4 + q : q < 15 ? 17 + (q - 13) : q < 17 ? 1 + (q - 15)
+         : q == 17 ? 22 : q == 18 ? 28 : q == 19 ? 20 : q == 20 ? 0 : q == 21 ? 21 : q == 22 ? 19 : q == 23 ? 3 : q == 24 ? 30 : 29;
+}
+
+template <bool FM, bool MOD>
+__device__ __forceinline__ void HotRow<FM, MOD>::put(int q, float v) const
+{
+    constexpr int QS = MOD ? 26 : 17;
+    if (!FM && flat) {
+        if (q == QS) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) st_off<float>(base, boff + (unsigned)(flat_col<MOD>(QS) + j) * 4u, ((int)v == j) ? 1.f : 0.f);
+        } else st_off<float>(base, boff + (unsigned)flat_col<MOD>(q) * 4u, v);
+    } else st_off<float>(base, boff + (unsigned)q * qbytes, v);
+}
+template <bool FM, bool MOD>
+__device__ __forceinline__ void HotRow<FM, MOD>::put_u(int q, float v) const
+{
+    if (!FM && flat) put(q, v);
+    else st_off<float>(base + (size_t)q * qbytes, boff, v);
+}
 
 // Row-major observations ([N][F], the reference's layout): a lane's row is 140 B away from its neighbour's, so per-feature
 // stores would be 64 scattered 4-byte writes each.  Instead every wave transposes its 64 rows through a private LDS tile and
@@ -946,22 +994,35 @@ struct HotRow {                  // observation row addressing: uniform base + 3
 typedef float vf4 __attribute__((ext_vector_type(4)));
 template <bool MOD>
 struct RowTile {
-    static constexpr int F = MOD ? 35 : 26;
-    static constexpr int N4 = 64 * F / 4;                  // float4 per wave block (560 / 416)
+    static constexpr int FC = MOD ? 35 : 26;               // canonical row width
+    static constexpr int FMAX = FC + 5;                    // SB3_FLAT: METH_STATUS one-hot (6 columns for 1)
+    static constexpr int QS = MOD ? 26 : 17;               // canonical column of METH_STATUS
     float* t;                                              // this wave's [64][F] tile
-    int lane;
-    __device__ __forceinline__ RowTile(float* tiles, int wave) : t(tiles + wave * 64 * F), lane(threadIdx.x & 63) {}
-    __device__ __forceinline__ void put(int q, float v) const { t[lane * F + q] = v; }
+    int lane, F;
+    bool flat;
+    __device__ __forceinline__ RowTile(float* tiles, int wave, bool flat_)
+        : t(tiles + wave * 64 * (flat_ ? FMAX : FC)), lane(threadIdx.x & 63), F(flat_ ? FMAX : FC), flat(flat_) {}
+    __device__ __forceinline__ void put(int q, float v) const
+    {
+        float* r = t + lane * F;
+        if (flat) {
+            if (q == QS) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) r[flat_col<MOD>(QS) + j] = ((int)v == j) ? 1.f : 0.f;
+            } else r[flat_col<MOD>(q)] = v;
+        } else r[q] = v;
+    }
     __device__ __forceinline__ void put_u(int q, float v) const { put(q, v); }
     // rows = address of the wave's first row; all 64 lanes of the wave must be live
     __device__ __forceinline__ void flush(float* rows) const
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const int n4 = 16 * F;                             // float4 per wave block (560 / 416; flat: 640 / 496)
 #pragma unroll
-        for (int j = 0; j < (N4 + 63) / 64; j++) {
+        for (int j = 0; j < (16 * FMAX + 63) / 64; j++) {
             const int g = lane + 64 * j;
-            if (g < N4) __builtin_nontemporal_store(((const vf4*)t)[g], (vf4*)rows + g);
+            if (g < n4) __builtin_nontemporal_store(((const vf4*)t)[g], (vf4*)rows + g);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1014,7 +1075,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
            uint8_t* __restrict__ done)
 {
     __shared__ HotLds L;
-    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * 64 * RowTile<MOD>::F];      // row-major: one tile per wave
+    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * 64 * RowTile<MOD>::FMAX];   // row-major / flat: one tile per wave
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
@@ -1032,12 +1093,12 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
     const float r = hot_back(P, R, Q, setc, e, live);
     const bool wave_full = __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // e_raw of lane 0: the wave's first env
     if (!FM && wave_full) {
-        const RowTile<MOD> tile(s_tile, threadIdx.x >> 6);
+        const RowTile<MOD> tile(s_tile, threadIdx.x >> 6, P.flat != 0);
         hot_store_obs<MOD>(tile, Q, R.flags & 7);
-        tile.flush(obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * RowTile<MOD>::F);
+        tile.flush(obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F);
     }
     if (live) {
-        if (FM || !wave_full) hot_store_obs<MOD>(HotRow<FM>(obs, P, e), Q, R.flags & 7);
+        if (FM || !wave_full) hot_store_obs<MOD>(HotRow<FM, MOD>(obs, P, e), Q, R.flags & 7);
         st_off<float>(rew, (unsigned)e * 4u, r);
         st_off<uint8_t>(done, (unsigned)e, 0);
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
@@ -1092,7 +1153,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
     const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256)
     float* s_tiles = (float*)((unsigned char*)slot + 2 * sizeof(PcSlot));               // row-major: one [64][F] tile per consumer wave
-    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)NP * RowTile<MOD>::F * 4);      // [T][NP] decoded actions of the launch
+    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)NP * P.F * 4);      // [T][NP] decoded actions of the launch
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
     const int lx = producer ? threadIdx.x : threadIdx.x - NP;
@@ -1233,12 +1294,12 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
             row.put_u(o + 8, sc.y);
         };
         if (!FM && wave_full) {                             // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
-            const RowTile<MOD> tile(s_tiles, (int)(threadIdx.x >> 6) - (NP >> 6));
+            const RowTile<MOD> tile(s_tiles, (int)(threadIdx.x >> 6) - (NP >> 6), P.flat != 0);
             emit(tile);
-            tile.flush((float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * RowTile<MOD>::F);
+            tile.flush((float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F);
         }
         if (live) {
-            if (FM || !wave_full) emit(HotRow<FM>((float*)obs_t, P, e));
+            if (FM || !wave_full) emit(HotRow<FM, MOD>((float*)obs_t, P, e));
             st_off<float>(rew_t, (unsigned)e * 4u, (float)rw);
             st_off<uint8_t>(done_t, (unsigned)e, 0);
         }
@@ -1309,7 +1370,7 @@ struct ptg_env {
     std::vector<double> Tvals;
     std::vector<int> tab_rows, rec_base;
     size_t rec_total = 0;
-    bool fast = false, fm = false;
+    bool fast = false, fm = false, flat = false;
     double* d_tape = nullptr;
     unsigned short* d_lut16 = nullptr;
     unsigned short* d_rkey = nullptr;   // temperature keys of all window records (k_rollout_pc producers)
@@ -1544,7 +1605,7 @@ HotParams make_hot_params(const ptg_env* h)
     HotParams F;
     memset(&F, 0, sizeof F);
     F.N = P.N; F.S = P.S; F.sim_step = P.sim_step; F.eps_sim_steps = P.eps_sim_steps; F.F = P.F; F.nT = P.nT; F.tape_len = P.tape_len;
-    F.track_changes = P.track_changes; F.key_cold_max = P.key_cold_max; F.key_hot_min = P.key_hot_min; F.key_standby_max = P.key_standby_max;
+    F.flat = h->flat ? 1 : 0; F.track_changes = P.track_changes; F.key_cold_max = P.key_cold_max; F.key_hot_min = P.key_hot_min; F.key_standby_max = P.key_standby_max;
     F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride;
     F.off_featB = h->off_featB; F.off_gasn = h->off_gasn; F.off_euan = h->off_euan; F.off_sc = h->off_sc; F.off_gas = h->off_gas; F.off_eua = h->off_eua;
     F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.noise_sigma = P.noise_sigma; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
@@ -1695,7 +1756,7 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     if (cfg->time_step_op <= 0 || cfg->sim_step <= 0 || cfg->price_ahead < 1 || cfg->price_ahead > 64)
         return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad sim_step / time_step_op / price_ahead");
     if (cfg->out_dtype != PTG_OUT_F32 && cfg->out_dtype != PTG_OUT_F64) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad out_dtype");
-    if (cfg->obs_layout != PTG_OBS_ROW_MAJOR && cfg->obs_layout != PTG_OBS_FEATURE_MAJOR) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad obs_layout");
+    if (cfg->obs_layout < PTG_OBS_ROW_MAJOR || cfg->obs_layout > PTG_OBS_SB3_FLAT) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad obs_layout");
     if (cfg->eps_sim_steps < 7) return set_err(nullptr, PTG_E_INVALID, "ptg_create: eps_sim_steps must be >= 7");
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -1719,6 +1780,31 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     if ((rc = build_tables(h, tables))) return fail(rc);
     if ((rc = build_market(h, sets, n_sets))) return fail(rc);
 
+    if (cfg->obs_layout == PTG_OBS_SB3_FLAT) {            // rows in SB3's flattened form: sub-spaces by sorted key, METH_STATUS one-hot
+        struct Sub { const char* key; int q0, width; };
+        const int PA = cfg->price_ahead;
+        std::vector<Sub> subs;
+        int o;
+        if (cfg->raw_modified) { subs.push_back({"Pot_Reward", 0, PA}); subs.push_back({"Part_Full", PA, PA}); o = 2 * PA; }
+        else { subs.push_back({"Elec_Price", 0, PA}); subs.push_back({"Gas_Price", PA, 2}); subs.push_back({"EUA_Price", PA + 2, 2}); o = PA + 4; }
+        const char* tail[9] = {"METH_STATUS", "T_CAT", "H2_in_MolarFlow", "CH4_syn_MolarFlow", "H2_res_MolarFlow", "H2O_DE_MassFlow",
+                               "Elec_Heating", "Temp_hour_enc_sin", "Temp_hour_enc_cos"};
+        for (int q = 0; q < 9; q++) subs.push_back({tail[q], o + q, 1});
+        std::sort(subs.begin(), subs.end(), [](const Sub& a, const Sub& b) { return strcmp(a.key, b.key) < 0; });    // Python sorted() of ASCII keys
+        std::vector<int> cmap(h->F, 0);
+        int c = 0;
+        for (const Sub& sb : subs) {
+            for (int j = 0; j < sb.width; j++) cmap[sb.q0 + j] = c + j;
+            c += (sb.q0 == o) ? 6 : sb.width;
+        }
+        if (PA == 13)
+            for (int q = 0; q < h->F; q++)
+                if (cmap[q] != (cfg->raw_modified ? flat_col<true>(q) : flat_col<false>(q))) { set_err(h, PTG_E_INVALID, "internal: flat column table mismatch at %d", q); return fail(PTG_E_INVALID); }
+        int* d_cmap;
+        if ((rc = dev_upload(h, &d_cmap, cmap.data(), cmap.size()))) return fail(rc);
+        P.cmap = d_cmap; P.q_stat = o;
+        h->F += 5; h->flat = true;
+    }
     P.N = n_envs; P.S = h->S; P.sim_step = cfg->sim_step; P.eps_sim_steps = cfg->eps_sim_steps; P.PA = cfg->price_ahead;
     P.F = h->F; P.mod = cfg->raw_modified; P.eps_len_d = cfg->eps_len_d; P.E = 0; P.ep_stride = 0; P.tape_len = 0;
     P.noise_inline = 0; P.noise_seed = 0; P.env_offset = 0; P.noise_sigma = cfg->noise;

@@ -47,7 +47,7 @@ class HipEngine:
         c = dict(consts)
         c.setdefault("t_cat_initial", 16.0)
         c["out_dtype"] = _lib.OUT_F64 if out_dtype == "float64" else _lib.OUT_F32
-        c["obs_layout"] = {"row": _lib.OBS_ROW_MAJOR, "feature": _lib.OBS_FEATURE_MAJOR}[obs_layout]
+        c["obs_layout"] = {"row": _lib.OBS_ROW_MAJOR, "feature": _lib.OBS_FEATURE_MAJOR, "sb3_flat": _lib.OBS_SB3_FLAT}[obs_layout]
         self.feature_major = obs_layout == "feature"
         for k in _lib.CONFIG_KEYS:
             setattr(cfg, k, c[k])

@@ -536,3 +536,49 @@ def test_hot_kernels_raw_features_and_launch_variants(layout, variant):
     assert np.array_equal(out["hot"][2], out["generic"][2])
     for f, v in out["generic"][3].items():
         assert np.array_equal(out["hot"][3][f], v), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw_modified,out_dtype", [("mod", "float32"), ("raw", "float32"), ("mod", "float64")])
+def test_sb3_flat_layout_equals_flattened_dict_observation(raw_modified, out_dtype):
+    """obs_layout="sb3_flat": rows are what SB3's CombinedExtractor feeds a MultiInputPolicy (sub-spaces in sorted key order,
+    Discrete(6) METH_STATUS one-hot).  stable-baselines3 (2.x, un-vendored, not installed here) is restated in
+    rl_ptg_amd.vec_env.sb3_flat_features; the native layout must equal that function applied to the row-major output, bit for
+    bit -- hot kernels (step + fused rollout, ragged last wave), generic kernels (float64, terminating steps with reset rows and
+    terminal observations) alike."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    from rl_ptg_amd.vec_env import sb3_flat_features
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=1, raw_modified=raw_modified, train_steps=200000)
+    n, K = 200, 300                                       # 1-day episodes: 139 steps -> two terminations inside
+    acts = np.random.default_rng(4).integers(0, 5, (K, n)).astype(np.int32)
+    res = {}
+    for layout in ("row", "sb3_flat"):
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=out_dtype, obs_layout=layout)
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        eng.set_noise_rng(8)
+        o0 = eng.reset().clone()
+        o, r, d = eng.rollout(acts[:250])
+        so, fo = [], []
+        for t in range(250, K):
+            oo, rr, dd = eng.step(acts[t], want_final=True)
+            eng.sync()
+            so.append(oo.clone())
+            if bool(dd.any()):
+                fo.append((dd.bool().clone(), eng.final_obs.clone()))
+        eng.sync()
+        res[layout] = (eng.obs_dim, o0, o, r.cpu().numpy(), d.cpu().numpy(), torch.stack(so), fo)
+        eng.close()
+    F = res["row"][0]
+    assert res["sb3_flat"][0] == F + 5 == (40 if raw_modified == "mod" else 31)
+    flat = lambda x: sb3_flat_features(x, raw_modified=raw_modified)
+    assert torch.equal(res["sb3_flat"][1], flat(res["row"][1]))
+    assert torch.equal(res["sb3_flat"][2], flat(res["row"][2]))
+    assert torch.equal(res["sb3_flat"][5], flat(res["row"][5]))
+    assert np.array_equal(res["sb3_flat"][3], res["row"][3]) and np.array_equal(res["sb3_flat"][4], res["row"][4])
+    assert int(res["row"][4].sum()) == n                  # every env terminated once inside the rollout ...
+    assert len(res["row"][6]) == 1 and len(res["sb3_flat"][6]) == 1      # ... and once more in the per-step part (step 278)
+    (dr, fr), (df, ff) = res["row"][6][0], res["sb3_flat"][6][0]
+    assert bool(dr.all()) and torch.equal(dr, df)
+    assert torch.equal(ff, flat(fr))                      # terminal observations in the flat layout
