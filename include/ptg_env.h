@@ -187,6 +187,25 @@ int ptg_set_state(ptg_env* env, int field, const void* in_host);
 int ptg_finished_episodes(ptg_env* env, double* returns_host, int32_t* lengths_host, int32_t* env_ids_host,
                           int cap, int* count);
 
+/* ---- VecNormalize(env, norm_obs=False) reward normalisation on the device ------------------------------------------
+ * Replaces: stable_baselines3.common.vec_env.VecNormalize.step_wait / _update_reward / normalize_reward and
+ * RunningMeanStd.update (SB3 2.0.0a13, the reference's pin; wrapped around the env in src/rl_utils.py:453), over a
+ * [T][N] reward matrix as ptg_rollout (T >= 1) or ptg_step (T = 1) writes it:
+ *   returns = returns * gamma + reward;  running moments of `returns` updated with the step's batch mean / variance;
+ *   reward_out = clip(reward / sqrt(var + epsilon), +-clip_reward);  returns[done] = 0.
+ * Two phases so that a job sharded over GPUs normalises with the moments of ALL envs: ptg_vn_batch_moments advances this
+ * handle's returns and yields per-step (count, mean, M2) of its envs; the caller merges the shards' moments (Chan's formula,
+ * rl_ptg_amd.dist.merge_moments -- one all-gather per rollout) and hands the merged [T][3] array to ptg_vn_apply, which
+ * updates the running statistics step by step and writes the normalised rewards.  moments_dev NULL = single-GPU: the
+ * handle's own moments are used. */
+int ptg_vn_init(ptg_env* env, double gamma, double epsilon, double clip_reward);      /* SB3 defaults: 0.99, 1e-8, 10.0 */
+int ptg_vn_batch_moments(ptg_env* env, const void* rew_dev, const uint8_t* done_dev, int n_steps, double* moments_dev, void* stream);
+int ptg_vn_apply(ptg_env* env, const void* rew_dev, int n_steps, const double* moments_dev, void* rew_out_dev, int training,
+                 void* stream);
+/* running statistics {mean, var, count} and the per-env discounted returns (either pointer may be NULL) */
+int ptg_vn_get(ptg_env* env, double* stats3_host, double* returns_host);
+int ptg_vn_set(ptg_env* env, const double* stats3_host, const double* returns_host);
+
 /* diagnostics for tests: the device-built lookup products */
 int ptg_debug_get_index_lut(ptg_env* env, double* T_values_host, int32_t* lut_host /*[6][nT]*/, int* n_T);
 int ptg_debug_window_record(ptg_env* env, int table_id, int start_row, double* out7_host /*T_last, 5 means, key*/);

@@ -1358,6 +1358,139 @@ __global__ void k_extract_keys(const RecFast* __restrict__ recf, unsigned short*
     if (g < n) rkey[g] = (unsigned short)recf[g].tkey;
 }
 
+// ================================================================================== VecNormalize reward normalisation
+// stable-baselines3 2.0.0a13 (the reference's pin, requirements.txt:5; un-vendored), vec_env/vec_normalize.py + running_mean_std.py,
+// as the reference uses it: VecNormalize(env, norm_obs=False) (src/rl_utils.py:453).  Per vector step:
+//   returns = returns * gamma + reward;  ret_rms.update(returns)   [batch mean / population variance over the envs, merged into
+//   the running moments];  reward_out = clip(reward / sqrt(ret_rms.var + epsilon), +-clip_reward);  returns[done] = 0.
+// Over a [T][N] reward matrix that is: a per-env recurrence with per-step moments over the envs (k_vn_moments, k_vn_merge), a
+// T-step scalar scan of the running moments (k_vn_scan) and an elementwise pass (k_vn_norm).  Moments travel as
+// (count, mean, M2) and are merged with Chan's formula -- across waves here, across GPUs in rl_ptg_amd/dist.py.
+__device__ __forceinline__ void chan_merge(double& ca, double& ma, double& Ma, double cb, double mb, double Mb)
+{
+    if (cb == 0.0) return;
+    if (ca == 0.0) { ca = cb; ma = mb; Ma = Mb; return; }
+    const double tot = ca + cb, delta = mb - ma;
+    ma = ma + delta * cb / tot;
+    Ma = Ma + Mb + delta * delta * ca * cb / tot;
+    ca = tot;
+}
+
+// Per-env recurrence + per-step moments of every wave (one wave per workgroup).  Cross-lane reductions per step would
+// dominate (a float64 butterfly is 12 dependent ds_bpermute or DPP stages: measured 0.33-0.46 us per step at one wave per SIMD),
+// so the work is transposed instead: for 64 steps at a time lane e runs the recurrence of ITS env and parks the 64 returns in
+// an LDS tile [step][env]; then lane t sums row t -- the moments of step t over the wave's envs -- in a private loop (two
+// passes: mean, then squared deviations) and writes that step's partial.  No cross-lane instruction at all.
+template <typename OUT>
+__global__ void __launch_bounds__(64)
+k_vn_moments(const OUT* __restrict__ rew, const uint8_t* __restrict__ done, int N, int T, double gamma, double* __restrict__ returns,
+             double* __restrict__ partials, int nW)
+{
+    constexpr int TS = 64, PITCH = 65;                      // 65: row t starts 2 banks after row t-1
+    __shared__ double tile[TS * PITCH];
+    const int lane = threadIdx.x, w = blockIdx.x;           // w = wave index = workgroup index
+    const int e_raw = w * 64 + lane;
+    const bool live = e_raw < N;
+    const int e = live ? e_raw : N - 1;
+    const int n_live = min(64, N - w * 64);
+    double ret = live ? returns[e] : 0.0;
+    for (int t0 = 0; t0 < T; t0 += TS) {
+        const int nt = min(TS, T - t0);
+        for (int tb = 0; tb < nt; tb += 8) {                // recurrence, loads batched eight steps at a time
+            OUT r[8]; uint8_t d[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const size_t g = (size_t)(t0 + min(tb + j, nt - 1)) * N + e;
+                r[j] = rew[g]; d[j] = done[g];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (tb + j < nt) {
+                    ret = ret * gamma + (double)r[j];       // _update_reward
+                    tile[(tb + j) * PITCH + lane] = ret;
+                    ret = d[j] ? 0.0 : ret;                 // self.returns[dones] = 0
+                }
+            }
+        }
+        __syncthreads();
+        if (lane < nt) {                                    // lane t: moments of step t0 + t over this wave's envs
+            const double* row = tile + lane * PITCH;
+            double s = 0.0;
+            for (int q = 0; q < n_live; q++) s += row[q];
+            const double mean = s / (double)n_live;         // np.mean
+            double m2 = 0.0;
+            for (int q = 0; q < n_live; q++) { const double dv = row[q] - mean; m2 += dv * dv; }
+            double* p = partials + ((size_t)(t0 + lane) * nW + w) * 3;
+            p[0] = (double)n_live; p[1] = mean; p[2] = m2;
+        }
+        __syncthreads();
+    }
+    if (live) returns[e] = ret;
+}
+
+__global__ void __launch_bounds__(64)
+k_vn_merge(const double* __restrict__ partials, int nW, double* __restrict__ moments)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    double c = 0.0, m = 0.0, M = 0.0;
+    for (int w = lane; w < nW; w += 64) {
+        const double* p = partials + ((size_t)t * nW + w) * 3;
+        chan_merge(c, m, M, p[0], p[1], p[2]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double cb = __shfl_xor(c, off, 64), mb = __shfl_xor(m, off, 64), Mb = __shfl_xor(M, off, 64);
+        // both partners must end with the same value: merge in a fixed (lower lane first) order
+        double ca = c, ma = m, Ma = M;
+        if (lane & off) { double tc = cb, tm = mb, tM = Mb; chan_merge(tc, tm, tM, ca, ma, Ma); c = tc; m = tm; M = tM; }
+        else { chan_merge(ca, ma, Ma, cb, mb, Mb); c = ca; m = ma; M = Ma; }
+    }
+    if (lane == 0) { moments[t * 3 + 0] = c; moments[t * 3 + 1] = m; moments[t * 3 + 2] = M; }
+}
+
+// RunningMeanStd.update_from_moments over the T steps of a launch; den[t] = sqrt(var + epsilon) AFTER the update of step t
+// (step_wait updates before it normalises).  update_from_moments IS Chan's merge of (count, mean, var * count), which is
+// associative: one wave runs it as a prefix scan (per-lane chunks of the steps, a 6-stage scan of the lane totals, then the
+// chunks again) -- a chain of ~2 T / 64 + 6 merges instead of T, each a float64 division.  training == 0: frozen statistics.
+__global__ void __launch_bounds__(64)
+k_vn_scan(const double* __restrict__ moments, int T, int training, double epsilon, double* __restrict__ stats, double* __restrict__ den)
+{
+    const int lane = threadIdx.x;
+    const double mean0 = stats[0], var0 = stats[1], count0 = stats[2];
+    const int chunk = (T + 63) / 64, t_lo = min(T, lane * chunk), t_hi = min(T, t_lo + chunk);
+    if (!training) {
+        for (int t = t_lo; t < t_hi; t++) den[t] = sqrt(var0 + epsilon);
+        return;
+    }
+    double c = 0.0, m = 0.0, M = 0.0;                       // this lane's chunk, merged
+    for (int t = t_lo; t < t_hi; t++) chan_merge(c, m, M, moments[t * 3 + 0], moments[t * 3 + 1], moments[t * 3 + 2]);
+    double ic = c, im = m, iM = M;                          // inclusive scan over the lanes (earlier steps first)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        double pc = __shfl_up(ic, off, 64), pm = __shfl_up(im, off, 64), pM = __shfl_up(iM, off, 64);
+        if (lane >= off) { chan_merge(pc, pm, pM, ic, im, iM); ic = pc; im = pm; iM = pM; }
+    }
+    double rc = __shfl_up(ic, 1, 64), rm = __shfl_up(im, 1, 64), rM = __shfl_up(iM, 1, 64);      // exclusive prefix
+    if (lane == 0) { rc = 0.0; rm = 0.0; rM = 0.0; }
+    double qc = count0, qm = mean0, qM = var0 * count0;     // running moments before this lane's first step
+    chan_merge(qc, qm, qM, rc, rm, rM);
+    for (int t = t_lo; t < t_hi; t++) {
+        chan_merge(qc, qm, qM, moments[t * 3 + 0], moments[t * 3 + 1], moments[t * 3 + 2]);
+        den[t] = sqrt(qM / qc + epsilon);
+    }
+    if (lane == 63) { stats[0] = qm; stats[1] = qM / qc; stats[2] = qc; }      // lane 63's prefix + chunk = all T steps
+}
+
+template <typename OUT>
+__global__ void __launch_bounds__(256)
+k_vn_norm(const OUT* __restrict__ rew, OUT* __restrict__ out, const double* __restrict__ den, int N, size_t total, double clip)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const double v = (double)rew[g] / den[g / (size_t)N];
+    out[g] = (OUT)fmin(fmax(v, -clip), clip);               // np.clip
+}
+
 }  // namespace
 
 // ================================================================================================= host side
@@ -1379,6 +1512,10 @@ struct ptg_env {
     std::vector<float> pool32_host;
     int* d_ladder = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
+    // VecNormalize reward normalisation (ptg_vn_*): per-env discounted returns, running (mean, var, count), scratch
+    double *vn_returns = nullptr, *vn_stats = nullptr, *vn_partials = nullptr, *vn_den = nullptr, *vn_moments = nullptr;
+    size_t vn_partials_cap = 0; int vn_T_cap = 0;
+    double vn_gamma = 0.99, vn_eps = 1e-8, vn_clip = 10.0;
     bool fin_maybe = false;      // a generic step ran since the last ptg_finished_episodes: only those can finish episodes
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
@@ -1745,6 +1882,9 @@ void ptg_destroy(ptg_env* env)
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->d_tape) (void)hipFree(env->d_tape);
     if (env->d_eps_ind) (void)hipFree(env->d_eps_ind);
+    if (env->vn_partials) (void)hipFree(env->vn_partials);
+    if (env->vn_den) (void)hipFree(env->vn_den);
+    if (env->vn_moments) (void)hipFree(env->vn_moments);
     delete env;
 }
 
@@ -2147,6 +2287,100 @@ int ptg_rollout_launches(ptg_env* h, int n_steps)
         }
     }
     return launches;
+}
+
+// ---- VecNormalize(norm_obs=False) on the device ---------------------------------------------------------------------
+int ptg_vn_init(ptg_env* h, double gamma, double epsilon, double clip_reward)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!(gamma >= 0.0) || !(epsilon >= 0.0) || !(clip_reward > 0.0)) return set_err(h, PTG_E_INVALID, "ptg_vn_init: bad gamma / epsilon / clip_reward");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if (!h->vn_returns) {
+        if ((rc = dev_alloc(h, &h->vn_returns, (size_t)h->n)) || (rc = dev_alloc(h, &h->vn_stats, 3))) return rc;
+    }
+    h->vn_gamma = gamma; h->vn_eps = epsilon; h->vn_clip = clip_reward;
+    const double st[3] = {0.0, 1.0, 1e-4};                  // RunningMeanStd(epsilon=1e-4): mean 0, var 1, count 1e-4
+    HIP_TRY(h, hipMemset(h->vn_returns, 0, sizeof(double) * h->n));
+    HIP_TRY(h, hipMemcpy(h->vn_stats, st, sizeof st, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int vn_scratch(ptg_env* h, int T)
+{
+    const int nW = (h->n + 63) / 64;
+    const size_t need = (size_t)T * nW * 3;
+    if (need > h->vn_partials_cap) {
+        if (h->vn_partials) (void)hipFree(h->vn_partials);
+        h->vn_partials = nullptr; h->vn_partials_cap = 0;
+        if (hipMalloc((void**)&h->vn_partials, need * sizeof(double)) != hipSuccess) return set_err(h, PTG_E_HIP, "hipMalloc of %zu bytes failed", need * sizeof(double));
+        h->vn_partials_cap = need;
+    }
+    if (T > h->vn_T_cap) {
+        if (h->vn_den) (void)hipFree(h->vn_den);
+        if (h->vn_moments) (void)hipFree(h->vn_moments);
+        h->vn_den = h->vn_moments = nullptr; h->vn_T_cap = 0;
+        if (hipMalloc((void**)&h->vn_den, sizeof(double) * T) != hipSuccess || hipMalloc((void**)&h->vn_moments, sizeof(double) * 3 * T) != hipSuccess)
+            return set_err(h, PTG_E_HIP, "hipMalloc failed");
+        h->vn_T_cap = T;
+    }
+    return 0;
+}
+
+int ptg_vn_batch_moments(ptg_env* h, const void* rew_dev, const uint8_t* done_dev, int n_steps, double* moments_dev, void* stream)
+{
+    if (!h || !rew_dev || !done_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "ptg_vn_batch_moments: bad argument");
+    if (!h->vn_returns) return set_err(h, PTG_E_INVALID, "ptg_vn_batch_moments: call ptg_vn_init first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = vn_scratch(h, n_steps))) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nW = (h->n + 63) / 64;
+    const dim3 grid(nW), block(64);
+    if (h->cfg.out_dtype == PTG_OUT_F64)
+        hipLaunchKernelGGL(k_vn_moments<double>, grid, block, 0, st, (const double*)rew_dev, done_dev, h->n, n_steps, h->vn_gamma, h->vn_returns, h->vn_partials, nW);
+    else
+        hipLaunchKernelGGL(k_vn_moments<float>, grid, block, 0, st, (const float*)rew_dev, done_dev, h->n, n_steps, h->vn_gamma, h->vn_returns, h->vn_partials, nW);
+    hipLaunchKernelGGL(k_vn_merge, dim3(n_steps), dim3(64), 0, st, h->vn_partials, nW, moments_dev ? moments_dev : h->vn_moments);
+    return launch_check(h, "k_vn_moments");
+}
+
+int ptg_vn_apply(ptg_env* h, const void* rew_dev, int n_steps, const double* moments_dev, void* rew_out_dev, int training, void* stream)
+{
+    if (!h || !rew_dev || !rew_out_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "ptg_vn_apply: bad argument");
+    if (!h->vn_returns) return set_err(h, PTG_E_INVALID, "ptg_vn_apply: call ptg_vn_init first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = vn_scratch(h, n_steps))) return rc;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_vn_scan, dim3(1), dim3(64), 0, st, moments_dev ? moments_dev : h->vn_moments, n_steps, training, h->vn_eps, h->vn_stats, h->vn_den);
+    const size_t total = (size_t)n_steps * h->n;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (h->cfg.out_dtype == PTG_OUT_F64)
+        hipLaunchKernelGGL(k_vn_norm<double>, grid, block, 0, st, (const double*)rew_dev, (double*)rew_out_dev, h->vn_den, h->n, total, h->vn_clip);
+    else
+        hipLaunchKernelGGL(k_vn_norm<float>, grid, block, 0, st, (const float*)rew_dev, (float*)rew_out_dev, h->vn_den, h->n, total, h->vn_clip);
+    return launch_check(h, "k_vn_norm");
+}
+
+int ptg_vn_get(ptg_env* h, double* stats3_host, double* returns_host)
+{
+    if (!h || !h->vn_returns) return set_err(h, PTG_E_INVALID, "ptg_vn_get: not initialised");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (stats3_host) HIP_TRY(h, hipMemcpy(stats3_host, h->vn_stats, sizeof(double) * 3, hipMemcpyDeviceToHost));
+    if (returns_host) HIP_TRY(h, hipMemcpy(returns_host, h->vn_returns, sizeof(double) * h->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ptg_vn_set(ptg_env* h, const double* stats3_host, const double* returns_host)
+{
+    if (!h || !h->vn_returns) return set_err(h, PTG_E_INVALID, "ptg_vn_set: not initialised");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (stats3_host) HIP_TRY(h, hipMemcpy(h->vn_stats, stats3_host, sizeof(double) * 3, hipMemcpyHostToDevice));
+    if (returns_host) HIP_TRY(h, hipMemcpy(h->vn_returns, returns_host, sizeof(double) * h->n, hipMemcpyHostToDevice));
+    return 0;
 }
 
 int ptg_sync(ptg_env* h, void* stream)

@@ -68,3 +68,36 @@ def all_gather_finished(returns, lengths, device=None, group=None):
         r_all.append(b[:c, 0])
         l_all.append(b[:c, 1].astype(np.int64))
     return np.concatenate(r_all), np.concatenate(l_all)
+
+
+def merge_moments(parts):
+    """Chan merge of per-shard moments: parts [world, T, 3] of (count, mean, M2) -> [T, 3], shards taken in rank order
+    (every rank computes the same floating-point result).  NumPy arrays or torch tensors."""
+    is_torch = hasattr(parts[0], "clone")
+    first = parts[0].clone() if is_torch else np.array(parts[0], dtype=np.float64)
+    c, m, M = first[..., 0], first[..., 1], first[..., 2]
+    for p in parts[1:]:
+        cb, mb, Mb = p[..., 0], p[..., 1], p[..., 2]
+        tot = c + cb
+        safe = tot + (tot == 0)                      # a step with no envs on either side stays (0, 0, 0)
+        delta = mb - m
+        m = m + delta * cb / safe
+        M = M + Mb + delta * delta * c * cb / safe
+        c = tot
+    if is_torch:
+        import torch
+        return torch.stack([c, m, M], dim=-1)
+    return np.stack([c, m, M], axis=-1)
+
+
+def all_merge_moments(moments, group=None):
+    """[T, 3] per-step (count, mean, M2) of this rank's envs -> the moments over all ranks' envs (identity without a process
+    group): one all-gather, then merge_moments."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return moments
+    import torch
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(moments) for _ in range(world)]
+    dist.all_gather(parts, moments.contiguous(), group=group)
+    return merge_moments(torch.stack(parts)).contiguous()

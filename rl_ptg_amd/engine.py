@@ -252,6 +252,44 @@ class HipEngine:
         n = cnt.value
         return r[:n], l[:n], ids[:n]
 
+    # ------------------------------------------------------------------ VecNormalize(norm_obs=False) on the device
+    def vn_init(self, gamma=0.99, epsilon=1e-8, clip_reward=10.0):
+        """Start reward normalisation as the reference wraps its envs (src/rl_utils.py:453, SB3 defaults)."""
+        self._chk(self._L.ptg_vn_init(self._h, float(gamma), float(epsilon), float(clip_reward)))
+
+    def vn_normalize(self, rew, done, training=True, out=None, group=None):
+        """Normalise a [T, N] (or [N]) reward tensor in place of VecNormalize.step_wait: advances the discounted returns,
+        updates the running moments step by step (training=True) and returns the clipped, scaled rewards.  With an
+        initialised torch.distributed process group the per-step moments of all ranks' envs are merged first (one
+        all-gather per call), so every rank holds the statistics of the whole job."""
+        torch = self._torch
+        from . import dist as ptg_dist
+        r2 = rew if rew.dim() == 2 else rew.unsqueeze(0)
+        d2 = done if done.dim() == 2 else done.unsqueeze(0)
+        T = r2.shape[0]
+        assert r2.shape == (T, self.n) and d2.shape == (T, self.n) and r2.is_contiguous() and d2.is_contiguous()
+        res = torch.empty_like(r2) if out is None else (out if out.dim() == 2 else out.unsqueeze(0))
+        with torch.cuda.device(self.device):
+            mom = None
+            if training:
+                mom = torch.empty((T, 3), dtype=torch.float64, device=self.device)
+                self._chk(self._L.ptg_vn_batch_moments(self._h, C.c_void_p(r2.data_ptr()), C.c_void_p(d2.data_ptr()), T,
+                                                       C.c_void_p(mom.data_ptr()), self._stream()))
+                mom = ptg_dist.all_merge_moments(mom, group=group)
+            self._chk(self._L.ptg_vn_apply(self._h, C.c_void_p(r2.data_ptr()), T, C.c_void_p(mom.data_ptr()) if mom is not None else None,
+                                           C.c_void_p(res.data_ptr()), 1 if training else 0, self._stream()))
+        return res if rew.dim() == 2 else res[0]
+
+    def vn_get(self):
+        st, ret = np.zeros(3), np.zeros(self.n)
+        self._chk(self._L.ptg_vn_get(self._h, _dp(st), _dp(ret)))
+        return dict(mean=st[0], var=st[1], count=st[2]), ret
+
+    def vn_set(self, stats=None, returns=None):
+        st = None if stats is None else np.array([stats["mean"], stats["var"], stats["count"]], dtype=np.float64)
+        rt = None if returns is None else np.ascontiguousarray(returns, dtype=np.float64)
+        self._chk(self._L.ptg_vn_set(self._h, None if st is None else _dp(st), None if rt is None else _dp(rt)))
+
     def debug_get_index_lut(self):
         nT = C.c_int(0)
         self._chk(self._L.ptg_debug_get_index_lut(self._h, None, None, C.byref(nT)))

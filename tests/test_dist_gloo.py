@@ -28,6 +28,10 @@ def _worker(rank, world, port, q):
         r = np.array([rank * 100.0 + i for i in range(rank + 2)])
         l = np.array([10 + i for i in range(rank + 2)])
         ra, la = ptg_dist.all_gather_finished(r, l)
+        # reward-normalisation moments: rank r holds envs [r*5, r*5+3+2r) of a ragged split; merged = moments over all envs
+        x = np.random.default_rng(42).normal(2.0, 3.0, (4, 8))[:, rank * 3:rank * 3 + 3 + 2 * rank]
+        mom = np.stack([np.full(4, x.shape[1], float), x.mean(1), ((x - x.mean(1, keepdims=True)) ** 2).sum(1)], -1)
+        merged = ptg_dist.all_merge_moments(torch.from_numpy(mom)).numpy()
         # the oracle stands in for the GPU engine: shard `rank` of a 6-env batch, episode order of the shared ep_index
         case = "synth_bs2_op2_term_penalty"
         tr, consts, tables, market = H.load_traj(case)
@@ -37,7 +41,7 @@ def _worker(rank, world, port, q):
         env = H.po.OracleVecEnv(consts, tables, market, n, ep_index0=first_ptr - n)   # constructor consumes n, reset the next n
         env.reset()
         ints, _ = env.state()
-        q.put((rank, ra.tolist(), la.tolist(), ints[:, 11].tolist(), (lo, hi), (first_ptr, stride)))
+        q.put((rank, ra.tolist(), la.tolist(), ints[:, 11].tolist(), (lo, hi), (first_ptr, stride), merged.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -54,9 +58,15 @@ def test_world_size_2_gloo():
         p.join(60)
         assert p.exitcode == 0
     exp_r = [0.0, 1.0, 100.0, 101.0, 102.0]
-    for rank, ra, la, act_d, rng, plan in out:
+    allx = np.random.default_rng(42).normal(2.0, 3.0, (4, 8))
+    for rank, ra, la, act_d, rng, plan, merged in out:
         assert ra == exp_r and la == [10, 11, 10, 11, 12]
         assert rng == (rank * 3, rank * 3 + 3) and plan == (6 + rank * 3, 6)
+        merged = np.array(merged)                   # both ranks hold the moments of all 8 envs (3 on rank 0 + 5 on rank 1)
+        assert merged[:, 0].tolist() == [8.0] * 4
+        np.testing.assert_allclose(merged[:, 1], allx.mean(1), rtol=1e-14)
+        np.testing.assert_allclose(merged[:, 2] / 8.0, allx.var(1), rtol=1e-13)
+    assert out[0][6] == out[1][6]                   # identical floating-point result on every rank
     # the episode every shard env starts in == what 6 reference envs sharing ep_index get (constructor 0..5, reset 6..11)
     tr, consts, tables, market = H.load_traj("synth_bs2_op2_term_penalty")
     full = H.po.OracleVecEnv(consts, tables, market, 6)
