@@ -992,20 +992,25 @@ __device__ __forceinline__ void HotRow<FM, MOD>::put_u(int q, float v) const
 // stores would be 64 scattered 4-byte writes each.  Instead every wave transposes its 64 rows through a private LDS tile and
 // writes them back as ONE contiguous block of 64 * F floats with dwordx4 stores (64 * 140 B = 70 full 128-byte lines).
 typedef float vf4 __attribute__((ext_vector_type(4)));
-template <bool MOD>
+template <bool MOD, bool FLAT>
 struct RowTile {
     static constexpr int FC = MOD ? 35 : 26;               // canonical row width
     static constexpr int FMAX = FC + 5;                    // SB3_FLAT: METH_STATUS one-hot (6 columns for 1)
+    static constexpr int F = FLAT ? FMAX : FC;
     static constexpr int QS = MOD ? 26 : 17;               // canonical column of METH_STATUS
-    float* t;                                              // this wave's [64][F] tile
-    int lane, F;
-    bool flat;
-    __device__ __forceinline__ RowTile(float* tiles, int wave, bool flat_)
-        : t(tiles + wave * 64 * (flat_ ? FMAX : FC)), lane(threadIdx.x & 63), F(flat_ ? FMAX : FC), flat(flat_) {}
+    static constexpr int N4 = 16 * F;                      // float4 per wave block (560 / 416; flat: 640 / 496)
+    // LDS row pitch: F = 40 would put lanes l and l + 4 on the same bank for every column (16-way conflicts on each of the 40
+    // writes: measured 2.15 us per step); 41 is conflict-free, and because 40 is a multiple of 4 a float4 of the output
+    // image never straddles two tile rows
+    static constexpr int PITCH = (F == 40) ? 41 : F;
+    static constexpr int TILE = 64 * PITCH;                // floats per wave
+    float* t;                                              // this wave's [64][PITCH] tile
+    int lane;
+    __device__ __forceinline__ RowTile(float* tiles, int wave) : t(tiles + wave * TILE), lane(threadIdx.x & 63) {}
     __device__ __forceinline__ void put(int q, float v) const
     {
-        float* r = t + lane * F;
-        if (flat) {
+        float* r = t + lane * PITCH;
+        if (FLAT) {
             if (q == QS) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) r[flat_col<MOD>(QS) + j] = ((int)v == j) ? 1.f : 0.f;
@@ -1018,11 +1023,18 @@ struct RowTile {
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int n4 = 16 * F;                             // float4 per wave block (560 / 416; flat: 640 / 496)
 #pragma unroll
-        for (int j = 0; j < (16 * FMAX + 63) / 64; j++) {
+        for (int j = 0; j < (N4 + 63) / 64; j++) {
             const int g = lane + 64 * j;
-            if (g < n4) __builtin_nontemporal_store(((const vf4*)t)[g], (vf4*)rows + g);
+            if (g < N4) {
+                vf4 v;
+                if (PITCH == F) v = ((const vf4*)t)[g];
+                else {
+                    const float* src = t + (g / (F / 4)) * PITCH + (g % (F / 4)) * 4;      // 4-byte aligned only
+                    v = vf4{src[0], src[1], src[2], src[3]};
+                }
+                __builtin_nontemporal_store(v, (vf4*)rows + g);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1075,7 +1087,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
            uint8_t* __restrict__ done)
 {
     __shared__ HotLds L;
-    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * 64 * RowTile<MOD>::FMAX];   // row-major / flat: one tile per wave
+    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * RowTile<MOD, true>::TILE];   // row-major / flat: one tile per wave
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
@@ -1093,9 +1105,9 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
     const float r = hot_back(P, R, Q, setc, e, live);
     const bool wave_full = __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // e_raw of lane 0: the wave's first env
     if (!FM && wave_full) {
-        const RowTile<MOD> tile(s_tile, threadIdx.x >> 6, P.flat != 0);
-        hot_store_obs<MOD>(tile, Q, R.flags & 7);
-        tile.flush(obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F);
+        float* rows = obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
+        if (P.flat) { const RowTile<MOD, true> tile(s_tile, threadIdx.x >> 6); hot_store_obs<MOD>(tile, Q, R.flags & 7); tile.flush(rows); }
+        else { const RowTile<MOD, false> tile(s_tile, threadIdx.x >> 6); hot_store_obs<MOD>(tile, Q, R.flags & 7); tile.flush(rows); }
     }
     if (live) {
         if (FM || !wave_full) hot_store_obs<MOD>(HotRow<FM, MOD>(obs, P, e), Q, R.flags & 7);
@@ -1153,7 +1165,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
     const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256)
     float* s_tiles = (float*)((unsigned char*)slot + 2 * sizeof(PcSlot));               // row-major: one [64][F] tile per consumer wave
-    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)NP * P.F * 4);      // [T][NP] decoded actions of the launch
+    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * (P.flat ? RowTile<MOD, true>::TILE : RowTile<MOD, false>::TILE) * 4);   // [T][NP] decoded actions
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
     const int lx = producer ? threadIdx.x : threadIdx.x - NP;
@@ -1294,9 +1306,10 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
             row.put_u(o + 8, sc.y);
         };
         if (!FM && wave_full) {                             // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
-            const RowTile<MOD> tile(s_tiles, (int)(threadIdx.x >> 6) - (NP >> 6), P.flat != 0);
-            emit(tile);
-            tile.flush((float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F);
+            float* rows = (float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
+            const int cw = (int)(threadIdx.x >> 6) - (NP >> 6);
+            if (P.flat) { const RowTile<MOD, true> tile(s_tiles, cw); emit(tile); tile.flush(rows); }
+            else { const RowTile<MOD, false> tile(s_tiles, cw); emit(tile); tile.flush(rows); }
         }
         if (live) {
             if (FM || !wave_full) emit(HotRow<FM, MOD>((float*)obs_t, P, e));
@@ -1787,7 +1800,7 @@ PcPlan pc_plan(const ptg_env* h)
     while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block) >= 256) pl.block *= 2;     // block/2 envs per workgroup
     if (getenv("PTG_BLOCK")) pl.block = atoi(getenv("PTG_BLOCK"));
     const int np = pl.block / 2;
-    if (!h->fm) pl.fixed += (size_t)np * h->F * 4;          // one [64][F] float tile per consumer wave
+    if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F) * 4;      // one [64][pitch] float tile per consumer wave (RowTile::PITCH)
     // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
     pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !getenv("PTG_NO_LDS_LUT");
     const size_t avail = pl.lds_max - pl.fixed - (pl.lds_lut ? pl.lut_bytes : 0) - 64;
