@@ -1081,13 +1081,15 @@ __device__ __forceinline__ void hot_fetch(const void* actions, size_t g, int& ri
 }
 
 // one vector step, no env terminates (host-guaranteed); lanes past N shadow env N-1 and store nothing
-template <bool FM, bool MOD, int NOISE, int ACTK>
+// LAY: 0 row-major, 1 feature-major, 2 SB3_FLAT rows (the PTG_OBS_* values)
+template <int LAY, bool MOD, int NOISE, int ACTK>
 __global__ void __launch_bounds__(256)
 k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* __restrict__ obs, float* __restrict__ rew,
            uint8_t* __restrict__ done)
 {
+    constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
     __shared__ HotLds L;
-    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * RowTile<MOD, true>::TILE];   // row-major / flat: one tile per wave
+    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * RowTile<MOD, FLAT>::TILE];   // row-major / flat: one tile per wave
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
@@ -1106,8 +1108,9 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
     const bool wave_full = __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // e_raw of lane 0: the wave's first env
     if (!FM && wave_full) {
         float* rows = obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
-        if (P.flat) { const RowTile<MOD, true> tile(s_tile, threadIdx.x >> 6); hot_store_obs<MOD>(tile, Q, R.flags & 7); tile.flush(rows); }
-        else { const RowTile<MOD, false> tile(s_tile, threadIdx.x >> 6); hot_store_obs<MOD>(tile, Q, R.flags & 7); tile.flush(rows); }
+        const RowTile<MOD, FLAT> tile(s_tile, threadIdx.x >> 6);
+        hot_store_obs<MOD>(tile, Q, R.flags & 7);
+        tile.flush(rows);
     }
     if (live) {
         if (FM || !wave_full) hot_store_obs<MOD>(HotRow<FM, MOD>(obs, P, e), Q, R.flags & 7);
@@ -1155,17 +1158,18 @@ __device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4,
     M.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
 }
 
-template <bool FM, bool MOD, int NOISE, int ACTK, bool LDSLUT, bool FULL>
+template <int LAY, bool MOD, int NOISE, int ACTK, bool LDSLUT, bool FULL>
 __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows)
 {
+    constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     HotLds& L = *(HotLds*)s_dyn;
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
     const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256)
     float* s_tiles = (float*)((unsigned char*)slot + 2 * sizeof(PcSlot));               // row-major: one [64][F] tile per consumer wave
-    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * (P.flat ? RowTile<MOD, true>::TILE : RowTile<MOD, false>::TILE) * 4);   // [T][NP] decoded actions
+    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * RowTile<MOD, FLAT>::TILE * 4);   // [T][NP] decoded actions
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
     const int lx = producer ? threadIdx.x : threadIdx.x - NP;
@@ -1308,8 +1312,9 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
         if (!FM && wave_full) {                             // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
             float* rows = (float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
             const int cw = (int)(threadIdx.x >> 6) - (NP >> 6);
-            if (P.flat) { const RowTile<MOD, true> tile(s_tiles, cw); emit(tile); tile.flush(rows); }
-            else { const RowTile<MOD, false> tile(s_tiles, cw); emit(tile); tile.flush(rows); }
+            const RowTile<MOD, FLAT> tile(s_tiles, cw);
+            emit(tile);
+            tile.flush(rows);
         }
         if (live) {
             if (FM || !wave_full) emit(HotRow<FM, MOD>((float*)obs_t, P, e));
@@ -1773,14 +1778,14 @@ bool hot_eligible(const ptg_env* h)
 
 int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
 
-template <bool FM, bool MOD, int NOISE>
+template <int LAY, bool MOD, int NOISE>
 void launch_step_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, float* obs, float* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
     const dim3 grid(grid_for(h->n, 256)), block(256);
-    if (kind == PTG_ACT_F32) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_F32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
-    else if (kind == PTG_ACT_I64) hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I64>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
-    else hipLaunchKernelGGL((k_step_hot<FM, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+    if (kind == PTG_ACT_F32) hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, PTG_ACT_F32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+    else if (kind == PTG_ACT_I64) hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, PTG_ACT_I64>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+    else hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
 }
 
 // Launch geometry of the fused hot rollout.  One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many
@@ -1808,7 +1813,7 @@ PcPlan pc_plan(const ptg_env* h)
     return pl;
 }
 
-template <bool FM, bool MOD, int NOISE>
+template <int LAY, bool MOD, int NOISE>
 void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
@@ -1832,7 +1837,7 @@ void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, i
             const bool full = m % np == 0;
 #define PTG_PC2(ACTK, LL, FULL)                                                                                       \
     do {                                                                                                              \
-        auto kfn = k_rollout_pc<FM, MOD, NOISE, ACTK, LL, FULL>;                                                      \
+        auto kfn = k_rollout_pc<LAY, MOD, NOISE, ACTK, LL, FULL>;                                                      \
         if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); \
         hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
     } while (0)
@@ -1846,20 +1851,19 @@ void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, i
     }
 }
 
+#define PTG_HOT_DISPATCH3(FN, LAY_, ...)                                                                 \
+    do {                                                                                                \
+        if (nm_ == NOISE_TAPE) { if (mod_) FN<LAY_, true, NOISE_TAPE>(__VA_ARGS__); else FN<LAY_, false, NOISE_TAPE>(__VA_ARGS__); }      \
+        else if (nm_ == NOISE_RNG) { if (mod_) FN<LAY_, true, NOISE_RNG>(__VA_ARGS__); else FN<LAY_, false, NOISE_RNG>(__VA_ARGS__); }    \
+        else { if (mod_) FN<LAY_, true, NOISE_NONE>(__VA_ARGS__); else FN<LAY_, false, NOISE_NONE>(__VA_ARGS__); }                        \
+    } while (0)
 #define PTG_HOT_DISPATCH(FN, ...)                                                                       \
     do {                                                                                                \
         const int nm_ = noise_mode(h);                                                                  \
-        const bool fm_ = h->fm, mod_ = h->P.mod != 0;                                                   \
-        if (nm_ == NOISE_TAPE) {                                                                        \
-            if (fm_) { if (mod_) FN<true, true, NOISE_TAPE>(__VA_ARGS__); else FN<true, false, NOISE_TAPE>(__VA_ARGS__); } \
-            else { if (mod_) FN<false, true, NOISE_TAPE>(__VA_ARGS__); else FN<false, false, NOISE_TAPE>(__VA_ARGS__); }   \
-        } else if (nm_ == NOISE_RNG) {                                                                  \
-            if (fm_) { if (mod_) FN<true, true, NOISE_RNG>(__VA_ARGS__); else FN<true, false, NOISE_RNG>(__VA_ARGS__); }   \
-            else { if (mod_) FN<false, true, NOISE_RNG>(__VA_ARGS__); else FN<false, false, NOISE_RNG>(__VA_ARGS__); }     \
-        } else {                                                                                        \
-            if (fm_) { if (mod_) FN<true, true, NOISE_NONE>(__VA_ARGS__); else FN<true, false, NOISE_NONE>(__VA_ARGS__); } \
-            else { if (mod_) FN<false, true, NOISE_NONE>(__VA_ARGS__); else FN<false, false, NOISE_NONE>(__VA_ARGS__); }   \
-        }                                                                                               \
+        const bool mod_ = h->P.mod != 0;                                                                \
+        if (h->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, __VA_ARGS__);                           \
+        else if (h->flat) PTG_HOT_DISPATCH3(FN, PTG_OBS_SB3_FLAT, __VA_ARGS__);                         \
+        else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, __VA_ARGS__);                                     \
     } while (0)
 
 hipStream_t as_stream(void* s) { return (hipStream_t)s; }
