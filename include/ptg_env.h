@@ -164,6 +164,11 @@ int ptg_step(ptg_env* env, const void* actions_dev, int action_kind, void* obs_d
  * stage (a few hundred); wider batches / longer rollouts are issued as consecutive launches on `stream`. */
 int ptg_rollout(ptg_env* env, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
                 uint8_t* done_dev, void* stream);
+/* ptg_rollout that also records the 24 _get_info fields of every step: info_dev [T][N][24] float64 (key order of
+ * env/ptg_gym_env.py:251-278, Meth_Action as its index).  Replaces: the per-step info dicts Postprocessing.test_performance
+ * collects into its stats array (src/rl_utils.py:528-565).  Runs the generic step kernel T times. */
+int ptg_rollout_info(ptg_env* env, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
+                     uint8_t* done_dev, double* info_dev, void* stream);
 /* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
  * per-launch timing); negative PTG_E_* on a bad argument. */
 int ptg_rollout_launches(ptg_env* env, int n_steps);

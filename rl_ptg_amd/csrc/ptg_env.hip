@@ -2286,6 +2286,21 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
     return 0;
 }
 
+int ptg_rollout_info(ptg_env* h, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
+                     uint8_t* done_dev, double* info_dev, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!actions_dev || !obs_dev || !rew_dev || !done_dev || !info_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "ptg_rollout_info: bad argument");
+    const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    for (int t = 0; t < n_steps; t++) {                     // info rows need the un-reduced reward terms: the generic step kernel, T launches
+        const int rc = ptg_step(h, (const char*)actions_dev + (size_t)t * h->n * asz, action_kind, (char*)obs_dev + (size_t)t * h->n * h->F * osz,
+                                (char*)rew_dev + (size_t)t * h->n * osz, done_dev + (size_t)t * h->n, nullptr,
+                                info_dev + (size_t)t * h->n * PTG_N_INFO, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int ptg_rollout_launches(ptg_env* h, int n_steps)
 {
     if (!h || n_steps < 1) return PTG_E_INVALID;

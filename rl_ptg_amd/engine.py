@@ -218,6 +218,24 @@ class HipEngine:
                                           C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
         return obs, rew, done
 
+    def rollout_info(self, actions):
+        """T steps with the 24 `_get_info` fields of every step recorded on the device: returns (obs, rew, done, info) with
+        info [T, N, 24] float64 in the key order of rl_ptg_amd.vec_env.INFO_KEYS (what Postprocessing.test_performance gathers
+        from per-step info dicts, src/rl_utils.py:528-565)."""
+        torch = self._torch
+        a = self.as_device_actions(actions)
+        assert a.dim() == 2 and a.shape[1] == self.n
+        T = a.shape[0]
+        with torch.cuda.device(self.device):
+            shape = (T, self.obs_dim, self.n) if self.feature_major else (T, self.n, self.obs_dim)
+            obs = torch.empty(shape, dtype=self.out_dtype, device=self.device)
+            rew = torch.empty((T, self.n), dtype=self.out_dtype, device=self.device)
+            done = torch.empty((T, self.n), dtype=torch.uint8, device=self.device)
+            info = torch.empty((T, self.n, 24), dtype=torch.float64, device=self.device)
+            self._chk(self._L.ptg_rollout_info(self._h, C.c_void_p(a.data_ptr()), self._action_kind(a), T, C.c_void_p(obs.data_ptr()),
+                                               C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(info.data_ptr()), self._stream()))
+        return obs, rew, done, info
+
     def rollout_launches(self, n_steps):
         """Kernel launches a rollout of n_steps would issue from the envs' current position (per-launch timing)."""
         k = self._L.ptg_rollout_launches(self._h, int(n_steps))

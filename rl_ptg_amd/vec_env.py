@@ -305,3 +305,16 @@ def sb3_flat_features(obs, raw_modified="mod", price_ahead=13, feature_major=Fal
             x = torch.nn.functional.one_hot(x[..., 0].round().long(), num_classes=6).to(obs.dtype)
         parts.append(x)
     return torch.cat(parts, dim=-1)
+
+
+def stats_table(info, done, stats_names=None):
+    """The `stats` array of the reference's Postprocessing.test_performance (src/rl_utils.py:528-565) from a recorded info
+    stream: info [T, 24] of ONE env (HipEngine.rollout_info(...)[3][:, e]), done [T]; rows of terminated steps stay zero, as
+    there.  Returns {stats_name: array [T]} in the column order of EnvConfig.stats_names (src/rl_config_env.py:44-49)."""
+    from .config import STATS_NAMES
+    names = list(STATS_NAMES if stats_names is None else stats_names)
+    a = np.asarray(info.cpu() if hasattr(info, "cpu") else info, dtype=np.float64).copy()
+    d = np.asarray(done.cpu() if hasattr(done, "cpu") else done).astype(bool)
+    assert a.ndim == 2 and a.shape[1] == len(INFO_KEYS) == len(names) and d.shape == (a.shape[0],)
+    a[d] = 0.0
+    return {nme: a[:, m] for m, nme in enumerate(names)}

@@ -582,3 +582,29 @@ def test_sb3_flat_layout_equals_flattened_dict_observation(raw_modified, out_dty
     (dr, fr), (df, ff) = res["row"][6][0], res["sb3_flat"][6][0]
     assert bool(dr.all()) and torch.equal(dr, df)
     assert torch.equal(ff, flat(fr))                      # terminal observations in the flat layout
+
+
+@pytest.mark.gpu
+def test_rollout_info_stream_equals_reference_infos():
+    """§8(f) rank 4: the 24 `_get_info` fields of every step recorded on the device ([T][N][24]) == the info dicts of the
+    unmodified reference (golden fixture), and the `stats` table Postprocessing.test_performance builds from them
+    (src/rl_utils.py:528-565: key order of stats_names, Meth_Action as its index, zero rows at terminated steps)."""
+    from rl_ptg_amd.vec_env import stats_table, INFO_KEYS
+    from rl_ptg_amd.config import STATS_NAMES
+    case = next(c for c in H.TRAJ_CASES if "infos" in H.load_traj(c)[0])
+    tr, eng = H.make_engine(case, "float64", obs_layout="row")
+    eng.reset()
+    obs, rew, done, info = eng.rollout_info(tr["actions"])
+    eng.sync()
+    K, n = tr["actions"].shape
+    assert tuple(info.shape) == (K, n, 24) and len(INFO_KEYS) == len(STATS_NAMES) == 24
+    np.testing.assert_allclose(info.cpu().numpy(), tr["infos"], rtol=RTOL64, atol=ATOL64)
+    assert np.array_equal(done.cpu().numpy(), tr["done"])
+    np.testing.assert_allclose(rew.cpu().numpy(), tr["f64s"][:, :, 0], rtol=RTOL64, atol=ATOL64)
+    tab = stats_table(info[:, 0], done[:, 0])
+    assert list(tab) == list(STATS_NAMES)
+    exp = tr["infos"][:, 0].copy()
+    exp[tr["done"][:, 0].astype(bool)] = 0.0
+    for m, nme in enumerate(STATS_NAMES):
+        np.testing.assert_allclose(tab[nme], exp[:, m], rtol=RTOL64, atol=ATOL64)
+    eng.close()
