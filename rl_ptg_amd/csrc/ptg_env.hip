@@ -380,7 +380,8 @@ struct ObsRow {
 #pragma unroll
                 for (int j = 0; j < 6; j++) p[c + j] = (OUT)(((int)v == j) ? 1 : 0);
             } else p[c] = v;
-        } else p[(size_t)q * stride] = v;
+        } else if (FM) __builtin_nontemporal_store(v, p + (size_t)q * stride);     // coalesced plane segments, never re-read: keep them out of L2
+        else p[(size_t)q * stride] = v;
     }
     __device__ __forceinline__ void copy_row_from(const ObsRow& src, int F) const     // same layout on both sides
     {
