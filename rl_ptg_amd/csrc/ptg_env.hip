@@ -5,11 +5,13 @@
 //                     catalyst temperature (:452-458), evaluated ONCE for every possible window start of every
 //                     table, with NumPy's pairwise summation order -> one 64-byte record per start row.
 //   k_build_argmin    _get_index (:514-523) for every distinct catalyst temperature x 6 destination tables.
-//   k_step / k_rollout  step() (:336-481) + DummyVecEnv auto-reset (reset :483-506) over a struct-of-arrays of N envs:
+//   k_step            step() (:336-481) + DummyVecEnv auto-reset (reset :483-506) over a struct-of-arrays of N envs:
 //                     one lane per env, integer state machine (:339-440), one record gather, reward (:280-334),
 //                     normalisation (:206-217), observation row (:219-249), info row (:251-278).
 //   k_reset           reset() (:483-506).
-//   k_fill_noise      the normal(0, noise) draws of :585/:599/:621 as a counter-based device RNG (Philox4x32-10).
+//   k_step_hot / k_rollout_pc   the float32 hot path of the same step (one launch per step / T fused steps).
+//   k_fill_noise      the normal(0, noise) draws of :585/:599/:621 as a counter-based device RNG (noise_draw).
+//   k_vn_*            VecNormalize(norm_obs=False) reward normalisation over the [T][N] rewards.
 // Built with -ffp-contract=off: the float64 expressions keep the reference's operand order.
 #include "../../include/ptg_env.h"
 
@@ -166,20 +168,27 @@ __global__ void k_build_records(const double* __restrict__ tab, const int* __res
     out[r] = rec;
 }
 
-// first index of min |T_r - Tq|  (ndarray.argmin keeps the first minimum)
-__global__ void k_build_argmin(const double* __restrict__ tab, int n, const double* __restrict__ Tvals, int nT,
-                               int* __restrict__ out)
+// first index of min |T_r - Tq|  (ndarray.argmin keeps the first minimum).  One wave per temperature key: lanes stride over the
+// table rows (each keeps its first strict minimum), then a butterfly picks the smallest distance, ties to the smaller row.
+__global__ void __launch_bounds__(256)
+k_build_argmin(const double* __restrict__ tab, int n, const double* __restrict__ Tvals, int nT, int* __restrict__ out)
 {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nT) return;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nT) return;                                    // whole wave
     const double t = Tvals[q];
-    int best = 0;
-    double bd = fabs(tab[1] - t);
-    for (int r = 1; r < n; r++) {
-        double d = fabs(tab[(size_t)r * NC + 1] - t);
+    int best = 0x7FFFFFFF;
+    double bd = INFINITY;
+    for (int r = lane; r < n; r += 64) {
+        const double d = fabs(tab[(size_t)r * NC + 1] - t);
         if (d < bd) { bd = d; best = r; }
     }
-    out[q] = best;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double od = __shfl_xor(bd, off, 64);
+        const int ob = __shfl_xor(best, off, 64);
+        if (od < bd || (od == bd && ob < best)) { bd = od; best = ob; }
+    }
+    if (lane == 0) out[q] = best;
 }
 
 // ------------------------------------------------------------------------------------------------ noise tape RNG
@@ -1656,7 +1665,7 @@ int build_tables(ptg_env* h, const ptg_tables* tb)
     }
     for (int d = 0; d < N_DEST; d++) {
         const int t = DEST_TID[d];
-        hipLaunchKernelGGL(k_build_argmin, dim3(grid_for(nT, 128)), dim3(128), 0, 0, d_raw + (size_t)raw_base[t] * NC,
+        hipLaunchKernelGGL(k_build_argmin, dim3(grid_for(nT, 4)), dim3(256), 0, 0, d_raw + (size_t)raw_base[t] * NC,
                            h->tab_rows[t], d_T, nT, d_arg + (size_t)d * nT);
         if ((rc = launch_check(h, "k_build_argmin"))) return rc;
     }
