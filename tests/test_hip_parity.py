@@ -608,3 +608,44 @@ def test_rollout_info_stream_equals_reference_infos():
     for m, nme in enumerate(STATS_NAMES):
         np.testing.assert_allclose(tab[nme], exp[:, m], rtol=RTOL64, atol=ATOL64)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_full_episode_rollout_hot_equals_generic_on_device():
+    """One whole 32-day episode and beyond (4 700 steps, termination + reset of the synchronised batch at step 4 602) at
+    N = 16 384 in ONE ptg_rollout call: the hot route (9 + 1 launches of the fused kernel around one generic terminating step) and
+    the all-generic route write bit-identical observations, rewards and done flags (compared on the device, 2 x 10.8 GB) and
+    leave identical state, returns and finished-episode lists."""
+    import os
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    from rl_ptg_amd.synthetic import sticky_actions_device
+    spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=32)
+    n, K = 16384, 4700
+    acts = sticky_actions_device(K, n, seed=77, device=torch.device("cuda", 0))
+    out = {}
+    for route in ("hot", "generic"):
+        if route == "generic":
+            os.environ["PTG_NO_HOT_KERNELS"] = "1"
+        try:
+            eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="feature")
+            eng.set_episode_plan(spec.eps_ind, n, n)
+            eng.set_noise_rng(123)
+            eng.reset()
+            if route == "hot":
+                assert eng.rollout_launches(K) == 9 + 1 + 1           # ceil(4602 / 512) hot launches (64-env workgroups), the terminating step, 97 more steps
+            o, r, d = eng.rollout(acts)
+            eng.sync()
+            fin = eng.finished_episodes()
+            st = {f: eng.get_state(f) for f in INT_FIELDS + ["cum_rew", "noise_count", "act_ep_d", "ep_ptr"]}
+            out[route] = (o, r, d, fin, st)
+            eng.close()
+        finally:
+            os.environ.pop("PTG_NO_HOT_KERNELS", None)
+    h, g = out["hot"], out["generic"]
+    assert torch.equal(h[0], g[0]) and torch.equal(h[1], g[1]) and torch.equal(h[2], g[2])
+    assert int(h[2].sum()) == n and int(h[2][4602].sum()) == n       # everybody terminates at k = eps_sim_steps - 6
+    assert sorted(zip(h[3][2].tolist(), h[3][0].tolist())) == sorted(zip(g[3][2].tolist(), g[3][0].tolist())) and len(h[3][0]) == n
+    for f, v in g[4].items():
+        assert np.array_equal(h[4][f], v), f
