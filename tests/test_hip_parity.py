@@ -649,3 +649,32 @@ def test_full_episode_rollout_hot_equals_generic_on_device():
     assert sorted(zip(h[3][2].tolist(), h[3][0].tolist())) == sorted(zip(g[3][2].tolist(), g[3][0].tolist())) and len(h[3][0]) == n
     for f, v in g[4].items():
         assert np.array_equal(h[4][f], v), f
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_fused_rollout_every_short_length():
+    """Rollout lengths 1..9 (the producer / consumer loops' prologue, peeled iteration, paired body and tail in every
+    combination; every wave must pass the same number of hand-off barriers) == per-step launches, bit for bit."""
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=8)
+    n = 300
+    rng = np.random.default_rng(31)
+    a = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="row")
+    b = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="row")
+    for e in (a, b):
+        e.set_episode_plan(spec.eps_ind, n, n)
+        e.set_noise_rng(6)
+        e.reset()
+    for T in list(range(1, 10)) + [17, 2, 1]:
+        acts = rng.integers(0, 5, (T, n)).astype(np.int32)
+        o, r, d = a.rollout(acts)
+        a.sync()
+        for t in range(T):
+            so, sr, sd = b.step(acts[t])
+            b.sync()
+            assert np.array_equal(o[t].cpu().numpy(), so.cpu().numpy()) and np.array_equal(r[t].cpu().numpy(), sr.cpu().numpy()), (T, t)
+    for f in INT_FIELDS + ["cum_rew", "noise_count"]:
+        assert np.array_equal(a.get_state(f), b.get_state(f)), f
+    a.close(); b.close()
