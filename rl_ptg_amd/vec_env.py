@@ -139,6 +139,20 @@ class PtGVecEnv(_VecEnvBase):
                 d[k] = float(v)
         return d
 
+    def _to_host(self, name, t):
+        """Enqueue a device -> host copy into a reusable pinned buffer (pageable if pinning is refused); no synchronisation."""
+        import torch
+        bufs = self.__dict__.setdefault("_hbufs", {})
+        b = bufs.get(name)
+        if b is None or b.shape != t.shape or b.dtype != t.dtype:
+            try:
+                b = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+            except RuntimeError:
+                b = torch.empty(tuple(t.shape), dtype=t.dtype)
+            bufs[name] = b
+        b.copy_(t, non_blocking=True)
+        return b
+
     # ------------------------------------------------------------------ VecEnv API
     def reset(self):
         obs = self.engine.rows(self.engine.reset()).cpu().numpy()
@@ -161,17 +175,23 @@ class PtGVecEnv(_VecEnvBase):
             raise RuntimeError("PtGVecEnv: call reset() before step()")
         eng = self.engine
         obs_t, rew_t, done_t = eng.step(self._actions)
+        # device -> pinned host staging on the step's stream, ONE synchronisation for the kernel and the copies; everything
+        # handed to the caller below is a fresh array (SB3 keeps the previous observation across the next step() call)
+        h_obs, h_rew, h_done = self._to_host("obs", eng.rows(obs_t)), self._to_host("rew", rew_t), self._to_host("done", done_t)
+        h_info = self._to_host("info", eng.info) if eng.info is not None else None
         eng.sync()                                            # raises on an invalid action (reference: IndexError)
-        obs = eng.rows(obs_t).cpu().numpy()
-        rews = rew_t.cpu().numpy().astype(np.float32)
-        dones = done_t.cpu().numpy().astype(bool)
+        obs = h_obs.numpy()
+        rews = h_rew.numpy().astype(np.float32)
+        dones = h_done.numpy().astype(bool)
         infos = [{} for _ in range(self.num_envs)]
-        if eng.info is not None:
-            info = eng.info.cpu().numpy()
+        if h_info is not None:
+            info = h_info.numpy()
             for e in range(self.num_envs):
                 infos[e] = self._info_dict(info[e])
         if dones.any():
-            final = eng.rows(eng.final_obs).cpu().numpy()
+            h_final = self._to_host("final", eng.rows(eng.final_obs))      # rare: only steps on which an episode ends
+            eng.sync()
+            final = h_final.numpy()
             r, l, ids = eng.finished_episodes()
             now = time.time()
             ep = {int(i): (float(rr), int(ll)) for rr, ll, i in zip(r, l, ids)}
