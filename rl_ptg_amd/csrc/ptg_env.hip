@@ -1072,29 +1072,29 @@ __device__ __forceinline__ void hot_stage_lds(const HotParams& P, HotLds& L)
 }
 
 // raw action -> action id; an invalid discrete action flags the error word and is replaced by the previous action
-template <int ACTK>
-__device__ __forceinline__ int hot_decode(const HotParams& P, int raw_i, float raw_f, unsigned flags)
+__device__ __forceinline__ int hot_decode(int actk, const HotParams& P, int raw_i, float raw_f, unsigned flags)
 {
     const int prev = (flags >> 12) & 7;
-    if (ACTK == PTG_ACT_F32) return decode_continuous(raw_f, prev);
+    if (actk == PTG_ACT_F32) return decode_continuous(raw_f, prev);
     const bool bad = (raw_i < -5) | (raw_i > 4);
     if (__ballot(bad)) { if (bad) atomicOr(P.err, 1); }
     return bad ? prev : (raw_i < 0 ? raw_i + 5 : raw_i);
 }
 
-template <int ACTK>
-__device__ __forceinline__ void hot_fetch(const void* actions, size_t g, int& ri, float& rf)
+// actk (PTG_ACT_*) is a launch-uniform kernel argument: the element type of the action buffer costs one scalar branch, not a
+// third of the kernel instantiations
+__device__ __forceinline__ void hot_fetch(int actk, const void* actions, size_t g, int& ri, float& rf)
 {
-    if (ACTK == PTG_ACT_F32) rf = ((const float*)actions)[g];
-    else if (ACTK == PTG_ACT_I64) { const long long v = ((const long long*)actions)[g]; ri = (v < -5 || v > 4) ? 99 : (int)v; }
+    if (actk == PTG_ACT_F32) rf = ((const float*)actions)[g];
+    else if (actk == PTG_ACT_I64) { const long long v = ((const long long*)actions)[g]; ri = (v < -5 || v > 4) ? 99 : (int)v; }
     else ri = ((const int*)actions)[g];
 }
 
 // one vector step, no env terminates (host-guaranteed); lanes past N shadow env N-1 and store nothing
 // LAY: 0 row-major, 1 feature-major, 2 SB3_FLAT rows (the PTG_OBS_* values)
-template <int LAY, bool MOD, int NOISE, int ACTK>
+template <int LAY, bool MOD, int NOISE>
 __global__ void __launch_bounds__(256)
-k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* __restrict__ obs, float* __restrict__ rew,
+k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0, float* __restrict__ obs, float* __restrict__ rew,
            uint8_t* __restrict__ done)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
@@ -1105,13 +1105,13 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int k0, float* _
     const int e = live ? e_raw : P.N - 1;
     const StA a = P.st_a[e]; const StB b = P.st_b[e];     // state + action loads in flight while LDS is staged
     int ri = 0; float rf = 0.f;
-    hot_fetch<ACTK>(actions, (size_t)e, ri, rf);
+    hot_fetch(actk, actions, (size_t)e, ri, rf);
     hot_stage_lds(P, L);
     __syncthreads();
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
     const double2 setc = P.setc[(R.flags >> 15) & 3];
-    const int act = hot_decode<ACTK>(P, ri, rf, R.flags);
+    const int act = hot_decode(actk, P, ri, rf, R.flags);
     HotLoads Q;
     hot_front<MOD, NOISE>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
     const float r = hot_back(P, R, Q, setc, e, live);
@@ -1168,9 +1168,9 @@ __device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4,
     M.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
 }
 
-template <int LAY, bool MOD, int NOISE, int ACTK, bool LDSLUT, bool FULL>
+template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL>
 __global__ void __launch_bounds__(512)
-k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
+k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
@@ -1201,7 +1201,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
         const int e_wg = e_base + blockIdx.x * NP;
         bool bad_any = false;           // flagged once after the loops: a ballot inside would keep them from unrolling
         auto code_of = [&](int ri, float rf) -> int {
-            if (ACTK == PTG_ACT_F32) return decode_continuous(rf, 7);
+            if (actk == PTG_ACT_F32) return decode_continuous(rf, 7);
             const bool bad = (ri < -5) | (ri > 4);
             bad_any |= bad;
             return bad ? 7 : (ri < 0 ? ri + 5 : ri);
@@ -1212,12 +1212,12 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
                 const int idx = q4 << 2, t = idx >> sh_np, x = idx & (NP - 1);
                 const size_t g = (size_t)t * P.N + e_wg + x;
                 int c[4];
-                if (ACTK == PTG_ACT_I64) {
+                if (actk == PTG_ACT_I64) {
                     const longlong2 v0 = *(const longlong2*)((const long long*)actions + g), v1 = *(const longlong2*)((const long long*)actions + g + 2);
                     const long long v[4] = {v0.x, v0.y, v1.x, v1.y};
 #pragma unroll
                     for (int j = 0; j < 4; j++) c[j] = code_of((v[j] < -5 || v[j] > 4) ? 99 : (int)v[j], 0.f);
-                } else if (ACTK == PTG_ACT_F32) {
+                } else if (actk == PTG_ACT_F32) {
                     const float4 v = *(const float4*)((const float*)actions + g);
                     c[0] = code_of(0, v.x); c[1] = code_of(0, v.y); c[2] = code_of(0, v.z); c[3] = code_of(0, v.w);
                 } else {
@@ -1232,7 +1232,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int k0, int T,
                 const int t = idx >> sh_np, x = idx & (NP - 1);
                 const int eg = min(e_wg + x, P.N - 1);
                 int ri = 0; float rf = 0.f;
-                hot_fetch<ACTK>(actions, (size_t)t * P.N + eg, ri, rf);
+                hot_fetch(actk, actions, (size_t)t * P.N + eg, ri, rf);
                 s_act[idx] = (unsigned char)code_of(ri, rf);
             }
         }
@@ -1793,9 +1793,7 @@ void launch_step_hot(const ptg_env* h, hipStream_t st, const void* actions, int 
 {
     const HotParams hp = make_hot_params(h);
     const dim3 grid(grid_for(h->n, 256)), block(256);
-    if (kind == PTG_ACT_F32) hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, PTG_ACT_F32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
-    else if (kind == PTG_ACT_I64) hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, PTG_ACT_I64>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
-    else hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, PTG_ACT_I32>), grid, block, 0, st, hp, actions, h->sync_k, obs, rew, done);
+    hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
 }
 
 // Launch geometry of the fused hot rollout.  One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many
@@ -1845,16 +1843,14 @@ void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, i
             const int m = std::min(chunk, h->n - e0);
             const dim3 grid(grid_for(m, np)), block(bs_all);
             const bool full = m % np == 0;
-#define PTG_PC2(ACTK, LL, FULL)                                                                                       \
+#define PTG_PC2(LL, FULL)                                                                                             \
     do {                                                                                                              \
-        auto kfn = k_rollout_pc<LAY, MOD, NOISE, ACTK, LL, FULL>;                                                      \
+        auto kfn = k_rollout_pc<LAY, MOD, NOISE, LL, FULL>;                                                           \
         if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); \
-        hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
+        hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
     } while (0)
-#define PTG_PC(ACTK, LL) do { if (full) PTG_PC2(ACTK, LL, true); else PTG_PC2(ACTK, LL, false); } while (0)
-            if (kind == PTG_ACT_F32) { if (ll) PTG_PC(PTG_ACT_F32, true); else PTG_PC(PTG_ACT_F32, false); }
-            else if (kind == PTG_ACT_I64) { if (ll) PTG_PC(PTG_ACT_I64, true); else PTG_PC(PTG_ACT_I64, false); }
-            else { if (ll) PTG_PC(PTG_ACT_I32, true); else PTG_PC(PTG_ACT_I32, false); }
+#define PTG_PC(LL) do { if (full) PTG_PC2(LL, true); else PTG_PC2(LL, false); } while (0)
+            if (ll) PTG_PC(true); else PTG_PC(false);
 #undef PTG_PC
 #undef PTG_PC2
         }
