@@ -922,7 +922,7 @@ __device__ __forceinline__ void hot_load_market(const HotParams& P, HotLoads& Q)
 
 // k1 = step count after this step: UNIFORM (the hot kernels only run on a synchronised batch), so the clock arithmetic of
 // :442-445 is scalar; only the episode offset act_ep_d differs between envs
-template <bool MOD, int NOISE, bool MARKET = true>
+template <bool MOD, int NOISE>
 __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
                                           HotRegs& R, int act, int e, int k1, HotLoads& Q)
 {
@@ -936,7 +936,7 @@ __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, c
     }
     const unsigned hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u, db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
     Q.hb4 = hb4; Q.db4 = db4; Q.kk8 = (unsigned)min(k1, P.eps_sim_steps) * 8u;
-    if (MARKET) hot_load_market<MOD>(P, Q);
+    hot_load_market<MOD>(P, Q);
     Q.el = ld_off<double>(P.pool64, hb4 * 2u);
     Q.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
     Q.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
