@@ -38,16 +38,11 @@ def algorithmic_bytes_per_env_step(obs_dim, out_bytes, path):
     return action + 2 * state + out
 
 
-def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
-    """Oracle (CPU restatement of the reference, oracle/ptg_oracle.c) timed on this host's cores: bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ptg_oracle as po
-    po.build()
+def _cpu_sample(po, spec, n_envs, n_steps, threads, seed):
     m = spec.markets[0]
     consts = dict(spec.consts, scenario=m["scenario"], rew_l_b=m["rew_l_b"], rew_u_b=m["rew_u_b"], r_0=m["r_0"])
     # eps_ind=None (episode offset 0): the synthetic trace has one episode, and n_envs reference envs would exhaust eps_ind
     market = dict(el=m["el"], pot_rew=m["pot_rew"], part_full=m["part_full"], gas=m["gas"], eua=m["eua"], eps_ind=None)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     env = po.OracleVecEnv(consts, spec.tables, market, n_envs, ep_index0=0)
     rng = np.random.default_rng(seed)
     env.set_noise_tape(rng.normal(0, consts["noise"], (n_envs, 256)))
@@ -59,14 +54,27 @@ def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
         cur = np.where(sw, rng.integers(0, 5, n_envs), cur)
         tapes.append(cur.astype(np.int32))
     for t in range(5):
-        env.step(tapes[t], n_threads=cores)
+        env.step_reuse(tapes[t], n_threads=threads)
     t0 = time.perf_counter()
     for t in range(5, n_steps):
-        env.step(tapes[t], n_threads=cores)
+        env.step_reuse(tapes[t], n_threads=threads)
     dt = time.perf_counter() - t0
     env.close()
-    return {"value": n_envs * (n_steps - 5) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ptg_oracle.c (OpenMP over envs), {n_envs} envs x {n_steps - 5} steps of the same workload, {dt:.1f} s wall"}
+    return n_envs * (n_steps - 5) / dt, dt
+
+
+def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
+    """Oracle (CPU restatement of the reference, oracle/ptg_oracle.c) timed on this host's cores: bounded samples, all cores
+    (the reported value) and one thread (SURVEY.md §8(d) asks for both)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ptg_oracle as po
+    po.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    v_all, dt_all = _cpu_sample(po, spec, n_envs, n_steps, cores, seed)
+    v_one, dt_one = _cpu_sample(po, spec, 1024, 65, 1, seed)
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ptg_oracle.c (OpenMP over envs), {n_envs} envs x {n_steps - 5} steps of the same workload, {dt_all:.1f} s wall",
+            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1, "sample": f"1024 envs x 60 steps, {dt_one:.1f} s wall"}}
 
 
 def main():

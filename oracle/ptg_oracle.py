@@ -220,6 +220,20 @@ class OracleVecEnv:
             self._chk(self._L.ptgo_step(self._h, a.ctypes.data, _dptr(obs), _dptr(rew), u8, _dptr(final), _dptr(info)))
         return obs, rew, done, final, info
 
+    def step_reuse(self, actions, n_threads=0):
+        """step() into buffers allocated once (throughput timing: no per-step allocation / zero-fill on the Python side)."""
+        b = self.__dict__.get("_bufs")
+        if b is None:
+            b = self._bufs = (np.zeros((self.n, self.obs_dim)), np.zeros(self.n), np.zeros(self.n, np.uint8), np.zeros((self.n, self.obs_dim)))
+        obs, rew, done, final = b
+        a = self._actions(actions)
+        u8 = done.ctypes.data_as(C.POINTER(C.c_uint8))
+        if n_threads and n_threads > 1:
+            self._chk(self._L.ptgo_step_mt(self._h, a.ctypes.data, _dptr(obs), _dptr(rew), u8, _dptr(final), None, int(n_threads)))
+        else:
+            self._chk(self._L.ptgo_step(self._h, a.ctypes.data, _dptr(obs), _dptr(rew), u8, _dptr(final), None))
+        return obs, rew, done, final, None
+
     def last(self):
         ints = np.zeros((self.n, 12), np.int64)
         f = np.zeros((self.n, 8))
