@@ -63,18 +63,33 @@ def _cpu_sample(po, spec, n_envs, n_steps, threads, seed):
     return n_envs * (n_steps - 5) / dt, dt
 
 
-def cpu_baseline(spec, n_envs=16384, n_steps=400, seed=7):
+def cpu_baseline(spec, n_envs=131072, n_steps=105, seed=7):
     """Oracle (CPU restatement of the reference, oracle/ptg_oracle.c) timed on this host's cores: bounded samples, all cores
     (the reported value) and one thread (SURVEY.md §8(d) asks for both)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ptg_oracle as po
     po.build()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    v_all, dt_all = _cpu_sample(po, spec, n_envs, n_steps, cores, seed)
-    v_one, dt_one = _cpu_sample(po, spec, 1024, 65, 1, seed)
+    try:                                                  # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) beats the visible core count
+        quota = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else int(q) / int(p)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / p
+        if quota:
+            cores = max(1, min(cores, int(quota + 0.5)))
+    except (OSError, ValueError):
+        pass
+    if cores <= 16:                                       # small hosts / quotas: keep the sample inside a few seconds
+        n_envs, n_steps = 65536, 305
+    v_all, dt_all = _cpu_sample(po, spec, n_envs, n_steps, cores, seed)        # >= 512 envs per thread and step on a 256-core host
+    v_one, dt_one = _cpu_sample(po, spec, 4096, 205, 1, seed)
     return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/ptg_oracle.c (OpenMP over envs), {n_envs} envs x {n_steps - 5} steps of the same workload, {dt_all:.1f} s wall",
-            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1, "sample": f"1024 envs x 60 steps, {dt_one:.1f} s wall"}}
+            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1, "sample": f"4096 envs x 200 steps, {dt_one:.1f} s wall"}}
 
 
 def main():
