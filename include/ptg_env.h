@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PTG_ABI_VERSION 1
+#define PTG_ABI_VERSION 2   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
