@@ -678,3 +678,41 @@ def test_fused_rollout_every_short_length():
     for f in INT_FIELDS + ["cum_rew", "noise_count"]:
         assert np.array_equal(a.get_state(f), b.get_state(f)), f
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["step_hot", "rollout_hot", "generic"])
+def test_price_index_past_the_series_is_an_error_not_an_out_of_bounds_read(route):
+    """An episode offset that pushes the 13-hour price window past the end of the series (reference: IndexError at
+    :446-447) is flagged as PTG_E_RANGE at the next sync by every kernel family; the kernels clamp the index instead of
+    reading out of bounds, and the other envs are unaffected."""
+    import os
+    from rl_ptg_amd.engine import HipEngine, PtgError
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=32)
+    n = 130
+    env = {"PTG_NO_HOT_KERNELS": "1"} if route == "generic" else {}
+    os.environ.update(env)
+    try:
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="feature")
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        eng.set_noise_rng(1)
+        eng.reset()
+        d = eng.get_state("act_ep_d")
+        d[77] = 10_000                                       # day 10 000 of a 38-day trace
+        eng.set_state("act_ep_d", d)
+        acts = np.full((8, n), 2, np.int32)
+        if route == "rollout_hot":
+            eng.rollout(acts)
+        else:
+            eng.step(acts[0])
+        with pytest.raises(PtgError) as ei:
+            eng.sync()
+        assert ei.value.code == -4
+        eng.step(acts[1])                                    # the flag was cleared by the sync that reported it ...
+        with pytest.raises(PtgError):
+            eng.sync()                                       # ... and the env is still out of range on the next step
+        eng.close()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
