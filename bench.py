@@ -163,8 +163,9 @@ def main():
         bufs = None
         if path == "rollout":
             oshape = (max(K, W, 1), F, n) if args.obs_layout == "feature" else (max(K, W, 1), n, F)
-            bufs = (torch.empty(oshape, dtype=eng.out_dtype, device=device), torch.empty((max(K, W, 1), n), dtype=eng.out_dtype, device=device),
-                    torch.empty((max(K, W, 1), n), dtype=torch.uint8, device=device))
+            # zero-filled once: every page of the output buffers has been written before the timed region
+            bufs = (torch.zeros(oshape, dtype=eng.out_dtype, device=device), torch.zeros((max(K, W, 1), n), dtype=eng.out_dtype, device=device),
+                    torch.zeros((max(K, W, 1), n), dtype=torch.uint8, device=device))
 
         def run(t0, cnt):
             if cnt <= 0:
