@@ -98,6 +98,9 @@ def all_merge_moments(moments, group=None):
         return moments
     import torch
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(moments) for _ in range(world)]
-    dist.all_gather(parts, moments.contiguous(), group=group)
-    return merge_moments(torch.stack(parts)).contiguous()
+    src = moments.contiguous()
+    if src.is_cuda and dist.get_backend(group) != "nccl":      # CPU-side backends (gloo rehearsals): collective on a host copy
+        src = src.cpu()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return merge_moments(torch.stack(parts)).to(moments.device).contiguous()
