@@ -247,6 +247,12 @@ def main():
                 return tj.get("step_bytes_per_launch")
             return tj["rollout_bytes_per_step"] * K / n_launch_of[path] if "rollout_bytes_per_step" in tj else None
         roof["traffic"] = traffic(args.path)
+        ppath = os.path.join(ROOT, "profiles", "hbm_probe_latest.json")
+        if os.path.exists(ppath):                     # stream rates measured on this chip next to the vendor peak
+            try:
+                roof["measured_stream_GBps"] = {k: v for k, v in json.load(open(ppath)).items() if k != "source"}
+            except Exception:
+                pass
         path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
                      "rollout": f"ptg_rollout, K steps fused ({n_launch_of['rollout']} kernel launch(es): <= 65536 envs x <= ~400 steps each)"}
         line = {
