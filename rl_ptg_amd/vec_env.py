@@ -47,7 +47,8 @@ class PtGVecEnv(_VecEnvBase):
     metadata = {"render_modes": ["None"]}
 
     def __init__(self, dict_input, n_envs, train_or_eval="train", seed=None, device=0, out_dtype="float64", obs_layout="row",
-                 noise="numpy", noise_tape_len=256, world_size=1, rank=0, render_mode="None", engine_cls=HipEngine):
+                 noise="numpy", noise_tape_len=256, world_size=1, rank=0, render_mode="None", engine_cls=HipEngine,
+                 norm_reward=False, gamma=0.99, epsilon=1e-8, clip_reward=10.0):
         spec = dict_input if isinstance(dict_input, EnvSpec) else EnvSpec.from_dict_input(dict_input, train_or_eval)
         self.spec = spec
         self.train_or_eval = train_or_eval
@@ -80,6 +81,22 @@ class PtGVecEnv(_VecEnvBase):
         self._t0 = time.time()
         self._ep_start = np.full(self.num_envs, self._t0)
         self._needs_reset = True
+        # norm_reward=True: step() returns rewards normalised as the reference's VecNormalize(env, norm_obs=False) wrapper does
+        # (src/rl_utils.py:453), computed on the device (HipEngine.vn_normalize); `training` = False freezes the statistics
+        self.norm_reward = bool(norm_reward)
+        self.training = True
+        self._old_reward = None
+        if self.norm_reward:
+            self.engine.vn_init(gamma=gamma, epsilon=epsilon, clip_reward=clip_reward)
+
+    def get_original_reward(self):
+        """Unnormalised rewards of the last step (VecNormalize.get_original_reward)."""
+        return None if self._old_reward is None else self._old_reward.copy()
+
+    @property
+    def ret_rms(self):
+        """Running moments of the discounted returns: dict(mean, var, count), as VecNormalize.ret_rms holds them."""
+        return self.engine.vn_get()[0] if self.norm_reward else None
 
     # ------------------------------------------------------------------ seeding / noise
     def _apply_seed(self, seed):
@@ -177,12 +194,17 @@ class PtGVecEnv(_VecEnvBase):
         obs_t, rew_t, done_t = eng.step(self._actions)
         # device -> pinned host staging on the step's stream, ONE synchronisation for the kernel and the copies; everything
         # handed to the caller below is a fresh array (SB3 keeps the previous observation across the next step() call)
+        raw_rew_t = rew_t
+        if self.norm_reward:                                  # same stream: moments, running statistics, clip(r / sqrt(var + eps))
+            rew_t = eng.vn_normalize(rew_t, done_t, training=self.training)
         h_obs, h_rew, h_done = self._to_host("obs", eng.rows(obs_t)), self._to_host("rew", rew_t), self._to_host("done", done_t)
+        h_raw = self._to_host("raw_rew", raw_rew_t) if self.norm_reward else None
         h_info = self._to_host("info", eng.info) if eng.info is not None else None
         eng.sync()                                            # raises on an invalid action (reference: IndexError)
         obs = h_obs.numpy()
         rews = h_rew.numpy().astype(np.float32)
         dones = h_done.numpy().astype(bool)
+        self._old_reward = h_raw.numpy().astype(np.float32) if h_raw is not None else rews
         infos = [{} for _ in range(self.num_envs)]
         if h_info is not None:
             info = h_info.numpy()

@@ -133,3 +133,35 @@ def test_sharded_reward_normalisation_equals_one_batch():
         np.testing.assert_allclose([st["mean"], st["var"], st["count"]], [st_full["mean"], st_full["var"], st_full["count"]], rtol=1e-11)
         h.close()
     full.close()
+
+
+@pytest.mark.gpu
+def test_vecenv_norm_reward_is_the_reference_wrapper():
+    """PtGVecEnv(..., norm_reward=True).step() == VecNormalize(PtGVecEnv(...), norm_obs=False).step() as restated from SB3:
+    normalised rewards, get_original_reward(), ret_rms, frozen statistics with training = False."""
+    from rl_ptg_amd.prep import synthetic_spec
+    from rl_ptg_amd.vec_env import PtGVecEnv
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=1, train_steps=200000)
+    n, K = 48, 160                                        # 139-step episodes: one termination inside
+    plain = PtGVecEnv(spec, n_envs=n, seed=5, noise="device")
+    wrapped = PtGVecEnv(spec, n_envs=n, seed=5, noise="device", norm_reward=True)
+    ora = vo.RewardNormalizer(n)
+    plain.reset(); wrapped.reset()
+    rng = np.random.default_rng(1)
+    for t in range(K):
+        a = rng.integers(0, 5, n)
+        _, r0, d0, _ = plain.step(a)
+        _, r1, d1, _ = wrapped.step(a)
+        exp = ora.step(r0.astype(np.float64), d0)
+        assert np.array_equal(d0, d1) and np.array_equal(wrapped.get_original_reward(), r0)
+        np.testing.assert_allclose(r1, exp, rtol=2e-6, atol=1e-30)
+    st = wrapped.ret_rms
+    # the oracle above is fed the float32 rewards the VecEnv hands out, the device normaliser the float64 ones: 1e-7 apart
+    np.testing.assert_allclose([st["mean"], st["var"], st["count"]], [ora.ret_rms.mean, ora.ret_rms.var, ora.ret_rms.count], rtol=1e-6)
+    wrapped.training = False
+    a = rng.integers(0, 5, n)
+    _, r0, _, _ = plain.step(a)
+    _, r1, _, _ = wrapped.step(a)
+    np.testing.assert_allclose(r1, np.clip(r0.astype(np.float64) / np.sqrt(st["var"] + 1e-8), -10, 10), rtol=2e-6, atol=1e-30)
+    assert wrapped.ret_rms == st
+    plain.close(); wrapped.close()
