@@ -34,7 +34,7 @@ meta = {}
 for f in glob.glob(f"gpurun_out/prof_{tag}_trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        trace[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        trace[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         meta[k] = {x: r[x] for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
 
 pmc = defaultdict(lambda: defaultdict(list))
@@ -51,12 +51,18 @@ lines = [f"# rocprofv3 summary, {tag}", "",
          "`bench.py --steps 100 --warmup 10 --launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads);",
          "counter unit KiB.", "",
          "| kernel | dispatches | avg us | min us | max us | VGPR | SGPR | LDS B | block | grid |", "|---|---|---|---|---|---|---|---|---|---|"]
-for k in sorted(trace, key=lambda x: -sum(trace[x])):
+for k in sorted(trace, key=lambda x: -sum(v[1] for v in trace[x])):
     if not any(k.startswith(o) for o in ours):
         continue
-    d, m = trace[k], meta[k]
+    d, m = [x[1] for x in sorted(trace[k])], meta[k]
     lines.append(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {min(d) / 1e3:.2f} | {max(d) / 1e3:.2f} | {m['VGPR_Count']} | {m['SGPR_Count']} | {m['LDS_Block_Size']} | {m['Workgroup_Size_X']} | {m['Grid_Size_X']} |")
+    if k == "k_rollout_pc" and len(d) > 1:
+        timed = d[1:]                                     # trace order: the first dispatch is the warm-up launch from reset
+        note = (f"`k_rollout_pc`: the {len(timed)} dispatches of the timed rollout average {sum(timed) / len(timed) / 1e3:.2f} us "
+                f"(bench.py's `roofline.avg_launch_us`, same launches without the profiler: 606-620 us); the warm-up launch from reset took {d[0] / 1e3:.2f} us.")
 traffic = {}
+if "note" in dir():
+    lines += ["", note]
 lines += ["", "| kernel | FETCH_SIZE KiB/launch (raw) | read bytes/launch (x2 corrected) | WRITE_SIZE KiB/launch | HBM bytes/launch |", "|---|---|---|---|---|"]
 for k in ("k_step_hot", "k_rollout_pc"):
     if k in pmc:
