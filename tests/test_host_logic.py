@@ -65,3 +65,20 @@ def test_env_spec_validation_and_merge():
     merged = EnvSpec.merge_scenarios([s1, spec, s3])
     assert [m["scenario"] for m in merged.markets] == [1, 2, 3]
     assert np.all(merged.markets[1]["gas"] == 15.0) and not merged.markets[2]["gas"].any() and not merged.markets[2]["eua"].any()
+
+
+def test_sticky_action_tape_holds_actions_between_switches():
+    """Synthetic workload generator: actions are uniform over {0..4} and change only at switch times drawn
+    with probability p_switch per step; p_switch = 1 is the i.i.d. tape."""
+    import torch
+    from rl_ptg_amd.synthetic import sticky_actions_device
+    a = sticky_actions_device(3000, 257, seed=3, device=torch.device("cpu"), p_switch=1.0 / 12.0).numpy()
+    assert a.shape == (3000, 257) and a.dtype == np.int32 and a.min() == 0 and a.max() == 4
+    changes = (a[1:] != a[:-1]).mean()
+    assert abs(changes - (1.0 / 12.0) * 0.8) < 0.004          # a switch redraws the same action one time in five
+    assert np.allclose(np.bincount(a.ravel(), minlength=5) / a.size, 0.2, atol=0.02)
+    b = sticky_actions_device(3000, 257, seed=3, device=torch.device("cpu"), p_switch=1.0 / 12.0).numpy()
+    assert np.array_equal(a, b)                                # reproducible
+    iid = sticky_actions_device(400, 64, seed=1, device=torch.device("cpu"), p_switch=1.0).numpy()
+    assert abs((iid[1:] != iid[:-1]).mean() - 0.8) < 0.02
+    assert sticky_actions_device(0, 5, seed=1, device=torch.device("cpu")).shape == (0, 5)
