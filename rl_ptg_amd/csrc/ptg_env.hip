@@ -2523,7 +2523,11 @@ int ptg_set_state(ptg_env* h, int field, const void* in_host)
     HIP_TRY(h, hipMemcpy(P.st_a, a.data(), sizeof(StA) * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(P.st_b, b.data(), sizeof(StB) * n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(P.st_c, c.data(), sizeof(StC) * n, hipMemcpyHostToDevice));
-    if (field == PTG_F_K) h->sync_k = -1;               // step counts set by hand: no longer known to be synchronised
+    if (field == PTG_F_K) {                             // step counts set by hand: synchronised again iff they are all equal
+        bool same = true;
+        for (int e = 1; e < n; e++) same = same && (a[e].k == a[0].k);
+        h->sync_k = (same && a[0].k >= 0 && a[0].k <= h->cfg.eps_sim_steps - 6) ? a[0].k : -1;
+    }
     return 0;
 }
 

@@ -157,10 +157,12 @@ class HipEngine:
         a = np.ascontiguousarray(tape, dtype=np.float64)
         assert a.ndim == 2 and a.shape[0] == self.n
         self._chk(self._L.ptg_set_noise_tape(self._h, _dp(a), a.shape[1]))
+        self._noise_cfg = {"mode": "tape", "per_env_len": int(a.shape[1])}
 
     def set_noise_rng(self, seed):
         """Draw the state-change noise inside the kernels from the counter-based generator (no tape)."""
         self._chk(self._L.ptg_set_noise_rng(self._h, int(seed) & (2 ** 64 - 1)))
+        self._noise_cfg = {"mode": "rng", "seed": int(seed) & (2 ** 64 - 1)}
 
     def set_global_env_offset(self, offset):
         self._chk(self._L.ptg_set_global_env_offset(self._h, int(offset)))
@@ -168,6 +170,7 @@ class HipEngine:
     def fill_noise_tape(self, seed, per_env_len):
         self._chk(self._L.ptg_fill_noise_tape(self._h, int(seed) & (2 ** 64 - 1), int(per_env_len), self._stream()))
         self.tape_len = int(per_env_len)
+        self._noise_cfg = {"mode": "tape", "per_env_len": int(per_env_len)}
 
     def get_noise_tape(self, per_env_len):
         out = np.zeros((self.n, per_env_len))
@@ -258,6 +261,40 @@ class HipEngine:
         a = np.ascontiguousarray(values, dtype=np.float64 if f >= 32 else np.int32)
         assert a.shape == (self.n,)
         self._chk(self._L.ptg_set_state(self._h, f, C.c_void_p(a.ctypes.data)))
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything a resumed run needs beyond the constructor arguments and the episode plan: every per-env state field,
+        the noise source and -- if started -- the reward normaliser (NumPy arrays / plain numbers; synchronises)."""
+        sd = {"fields": {k: self.get_state(k) for k in _lib.STATE_FIELDS}, "n": self.n}
+        sd["noise"] = dict(self.__dict__.get("_noise_cfg", {"mode": "none"}))
+        if sd["noise"].get("mode") == "tape":
+            sd["noise"]["tape"] = self.get_noise_tape(sd["noise"]["per_env_len"])
+        try:
+            st, ret = self.vn_get()
+            sd["vn"] = {"stats": st, "returns": ret}
+        except PtgError:
+            pass
+        return sd
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict() on an engine built with the same arguments (reset() first, then the episode plan)."""
+        assert sd["n"] == self.n
+        nz = sd.get("noise", {})
+        if nz.get("mode") == "rng":
+            self.set_noise_rng(nz["seed"])
+        elif nz.get("mode") == "tape":
+            self.set_noise_tape(nz["tape"])
+        for k, v in sd["fields"].items():
+            if k != "k":
+                self.set_state(k, v)
+        self.set_state("k", sd["fields"]["k"])              # last: equal step counts mark the batch as synchronised again
+        if "vn" in sd:
+            try:
+                self.vn_get()
+            except PtgError:
+                self.vn_init()
+            self.vn_set(stats=sd["vn"]["stats"], returns=sd["vn"]["returns"])
 
     def finished_episodes(self, cap=None):
         cap = 2 * self.n if cap is None else int(cap)

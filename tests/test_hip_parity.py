@@ -716,3 +716,46 @@ def test_price_index_past_the_series_is_an_error_not_an_out_of_bounds_read(route
     finally:
         for k in env:
             os.environ.pop(k, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise", ["rng", "tape"])
+def test_checkpoint_resume_continues_bit_identically(noise):
+    """state_dict() after 120 steps -> a fresh engine -> load_state_dict(): the next 100 steps (fused, hot path: equal step
+    counts mark the batch as synchronised again) and the reward normaliser continue exactly where the first engine would."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=3, operation="OP2", eps_len_d=2, train_steps=400000, state_change_penalty=0.1)
+    n = 320
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 5, (220, n)).astype(np.int32)
+
+    def make():
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="row")
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        if noise == "rng":
+            eng.set_noise_rng(77)
+        else:
+            eng.fill_noise_tape(seed=77, per_env_len=64)
+        eng.reset()
+        eng.vn_init()
+        return eng
+
+    a = make()
+    _, r, d = a.rollout(acts[:120])
+    a.vn_normalize(r, d)
+    sd = a.state_dict()
+    oa, ra, da = a.rollout(acts[120:])
+    na = a.vn_normalize(ra, da)
+    b = make()
+    b.load_state_dict(sd)
+    assert b.rollout_launches(100) == 1                    # the hot fused kernel, not 100 generic launches
+    ob, rb, db = b.rollout(acts[120:])
+    nb = b.vn_normalize(rb, db)
+    a.sync(); b.sync()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(na, nb)
+    for f in INT_FIELDS + ["cum_rew", "noise_count", "n_state_changes", "ep_ptr", "act_ep_d"]:
+        assert np.array_equal(a.get_state(f), b.get_state(f)), f
+    assert a.vn_get()[0] == b.vn_get()[0]
+    a.close(); b.close()
