@@ -6,11 +6,20 @@ N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-
 (one rank per GPU, RCCL).  Weak scaling: every rank owns --envs (default 65 536) envs; no per-step communication;
 one all-gather of finished-episode returns closes the timed region.
 
-A "step" is one vector step of the hot path over the whole batch (N_envs env-steps per rank): `ptg_step` launches
-(default, the drop-in VecEnv path) or one fused `ptg_rollout` launch of K steps (--path rollout).  Actions, state,
-observations, rewards and done flags are resident in HBM; nothing crosses PCIe inside the timed region.
+A "step" is one vector step of the hot path over the whole batch (N_envs env-steps per rank).  Headline: `ptg_rollout`
+(K steps fused into as few launches as fit) writing ROW-MAJOR [N, F] float32 observations -- the layout of the boundary
+(DummyVecEnv hands SB3 one row per env).  `also`: the same rollout with feature-major [F, N] observations, and `ptg_step`
+(one launch per vector step, the K launches replayed as one hipGraph).  Actions, state, observations, rewards and done
+flags are resident in HBM; nothing crosses PCIe inside the timed region.
 Workload: BASELINE.json configs[2] -- N = 65 536 envs, BS1/OP1, synthetic 38-day trace (32-day episodes), 'mod'
-features, discrete sticky actions, device-RNG noise tape.
+features, discrete sticky actions, in-kernel counter RNG for the state-change noise.
+
+Timing.  `value` is wall clock over the K timed steps (barrier + synchronize on both sides).  `roofline` uses the
+kernel's own duration: every timed launch carries a HIP event pair stamped at the kernel's begin and end
+(ptg_profile, hipExtLaunchKernelGGL) -- what rocprofv3 --kernel-trace reports for the dispatch -- because an event
+recorded from Python on an idle stream also counts the host's launch latency (20 us of the 55 us round 1 reported
+for 20 steps).  `roofline` = the K timed steps exactly as the driver asked for them (few steps right after a reset:
+launch prologue and drain are not amortised); `steady_state` = a 400-step launch run after the timed region.
 """
 import argparse
 import json
@@ -30,8 +39,8 @@ def algorithmic_bytes_per_env_step(obs_dim, out_bytes, path):
     """Compulsory HBM bytes per env-step of the shipped SoA layout.  Process tables, price series and
     the noise tape are cache-resident and not counted."""
     action = 4                               # int32 action
-    state = 16 + 16                          # StA {i, j, k, flags} + StB {cum_rew f64, act_ep_d, n_changes}; StC {noise_ctr, ep_ptr}
-                                             # is touched on state changes / resets only and is not counted
+    state = 16 + 16                          # StA {i, j, k, flags} + StB {cum_rew f64, act_ep_d, noise_ctr}; StC {n_changes, ep_ptr}
+                                             # is touched on penalised state changes / resets only and is not counted
     out = obs_dim * out_bytes + out_bytes + 1    # obs row + reward + done
     if path == "rollout":                    # state stays in registers between the steps of one launch
         return action + out
@@ -89,7 +98,11 @@ def cpu_baseline(spec, n_envs=131072, n_steps=105, seed=7):
     v_one, dt_one = _cpu_sample(po, spec, 4096, 205, 1, seed)
     return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/ptg_oracle.c (OpenMP over envs), {n_envs} envs x {n_steps - 5} steps of the same workload, {dt_all:.1f} s wall",
-            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1, "sample": f"4096 envs x 200 steps, {dt_one:.1f} s wall"}}
+            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1, "sample": f"4096 envs x 200 steps, {dt_one:.1f} s wall"},
+            # the reference's own Python cannot travel to the GPU box; its figure is the survey's, reported only
+            "reference_python": {"value": [1.0e4, 1.8e4], "unit": "env-steps/s per core", "measured_in_this_run": False,
+                                 "host": "build container, 1 of 8 vCPU Intel Xeon @ 2.10 GHz, unmodified env/ptg_gym_env.py, 1 env",
+                                 "source": "BASELINE.md section 3 (random actions 1.03e4 ... held actions 1.79e4)"}}
 
 
 def main():
@@ -99,15 +112,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--path", choices=["step", "rollout"], default="rollout",
-                    help="timed path: ptg_rollout (K steps fused in one launch) or ptg_step (one launch per step); the other one is "
-                         "measured too and reported under \"also\" (--no-also to skip)")
+                    help="timed path: ptg_rollout (K steps fused) or ptg_step (one launch per step); the other legs go under \"also\"")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step path: replay the K launches as one hipGraph, or launch eagerly")
     ap.add_argument("--no-also", dest="also", action="store_false")
+    ap.add_argument("--no-steady", dest="steady", action="store_false", help="skip the 400-step steady-state launch after the timed region")
     ap.add_argument("--scenario", type=int, default=1)
     ap.add_argument("--operation", default="OP1")
     ap.add_argument("--out-dtype", choices=["float32", "float64"], default="float32")
-    ap.add_argument("--obs-layout", choices=["row", "feature", "sb3_flat"], default="feature",
-                    help="observation matrix layout: feature-major [F][N] (coalesced SoA stores), row-major [N][F], or SB3's flattened [N][F+5] rows")
+    ap.add_argument("--obs-layout", choices=["row", "feature", "sb3_flat"], default="row",
+                    help="observation matrix layout: row-major [N][F] (the boundary's), feature-major [F][N], or SB3's flattened [N][F+5] rows")
     ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
     ap.add_argument("--noise", choices=["rng", "tape"], default="rng", help="in-kernel counter RNG or a device-filled tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,13 +157,12 @@ def main():
     n_total = n * world
     spec, _ = synthetic_spec(scenario=args.scenario, operation=args.operation, eps_len_d=32)
     first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
-    F = None
+    STEADY_T = 400
 
-    def measure(path, launch):
-        """W warm-up steps, then exactly K timed steps of `path`; returns (wall seconds, device ms, finished episodes)."""
-        nonlocal F
+    def measure(path, launch, layout, out_dtype, steady):
+        """W warm-up steps, then exactly K timed steps of `path`.  Returns a dict: wall seconds, per-launch kernel times, ..."""
         torch.cuda.empty_cache()                              # each leg starts from a fresh allocator state (no recycled multi-GB blocks)
-        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=out_dtype, obs_layout=layout)
         F = eng.obs_dim
         eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
         eng.set_global_env_offset(first_ptr - n_total)
@@ -158,14 +170,16 @@ def main():
             eng.set_noise_rng(seed=20250614)                  # counter-based draws inside the kernels
         else:
             eng.fill_noise_tape(seed=20250614, per_env_len=min(max(K + W + 8, 64), 1024))
-        actions = sticky_actions_device(K + W, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
+        extra = STEADY_T * 2 if (steady and path == "rollout") else 0
+        actions = sticky_actions_device(K + W + extra, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
         eng.reset()
         bufs = None
         if path == "rollout":
-            oshape = (max(K, W, 1), F, n) if args.obs_layout == "feature" else (max(K, W, 1), n, F)
+            rows = max(K, W, STEADY_T if extra else 1)
+            oshape = (rows, F, n) if layout == "feature" else (rows, n, F)
             # zero-filled once: every page of the output buffers has been written before the timed region
-            bufs = (torch.zeros(oshape, dtype=eng.out_dtype, device=device), torch.zeros((max(K, W, 1), n), dtype=eng.out_dtype, device=device),
-                    torch.zeros((max(K, W, 1), n), dtype=torch.uint8, device=device))
+            bufs = (torch.zeros(oshape, dtype=eng.out_dtype, device=device), torch.zeros((rows, n), dtype=eng.out_dtype, device=device),
+                    torch.zeros((rows, n), dtype=torch.uint8, device=device))
 
         def run(t0, cnt):
             if cnt <= 0:
@@ -191,6 +205,8 @@ def main():
             torch.cuda.current_stream(device).wait_stream(side)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_launch = eng.rollout_launches(K) if path == "rollout" else K        # kernel launches inside the timed region
+        if graph is None:
+            eng.profile(True)                                 # kernel-attached begin / end events on every timed launch
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -201,75 +217,129 @@ def main():
         else:
             run(W, K)
         ev1.record()
-        r, l, _ = eng.finished_episodes()          # synchronises; episodic-return reduction (one all-gather, off the step path)
+        r, l, _ = eng.finished_episodes()          # synchronises only if an episode can have ended; episodic-return reduction (one all-gather)
         r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t_start
         eng.sync()
-        dev_ms = ev0.elapsed_time(ev1)
+        span_ms = ev0.elapsed_time(ev1)                       # stream events around the whole timed region (includes host launch latency)
+        launch_us = None
+        if graph is None:
+            launch_us = eng.profile_read()
+            eng.profile(False)
+        res = {"elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "n_launch": n_launch, "n_fin": len(r_all), "F": F, "steady": None}
+        if extra:                                             # steady state: two more 400-step launches, the second one counted
+            eng.profile(True)
+            for q in range(2):
+                t0 = W + K + q * STEADY_T
+                eng.rollout(actions[t0:t0 + STEADY_T], bufs[0][:STEADY_T], bufs[1][:STEADY_T], bufs[2][:STEADY_T])
+            us = eng.profile_read()
+            eng.profile(False)
+            per = len(us) // 2
+            res["steady"] = {"steps": STEADY_T, "launch_us": [float(u) for u in us[per:]]}
         if world > 1:
-            tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=coll_device)
+            dev_sum = float(np.sum(launch_us)) if launch_us is not None else span_ms * 1e3
+            tmax = torch.tensor([elapsed, dev_sum], dtype=torch.float64, device=coll_device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed, dev_ms = float(tmax[0]), float(tmax[1])
+            res["elapsed"] = float(tmax[0])
+            if launch_us is not None and len(launch_us):
+                launch_us = launch_us * (float(tmax[1]) / max(dev_sum, 1e-9))      # slowest rank's device time, same launch count
+                res["launch_us"] = launch_us
+            else:
+                res["span_ms"] = float(tmax[1]) * 1e-3
         eng.close()
-        return elapsed, dev_ms, len(r_all), n_launch
+        return res
 
-    def roofline(path, dev_ms, out_bytes, launches):
-        b_alg = algorithmic_bytes_per_env_step(F, out_bytes, path)
-        per_launch_s = dev_ms * 1e-3 / launches
-        bytes_per_launch = b_alg * n * K / launches           # a rollout launch covers K / launches steps (of <= 65 536 envs each)
+    def roofline(path, res, out_bytes, steps):
+        b_alg = algorithmic_bytes_per_env_step(res["F"], out_bytes, path)
+        if res["launch_us"] is not None and len(res["launch_us"]):
+            per_launch_s = float(np.mean(res["launch_us"])) * 1e-6
+            launches, how = len(res["launch_us"]), "HIP events attached to each timed kernel launch (ptg_profile)"
+        else:                                                 # graph replay: stream events around the K back-to-back launches
+            launches = res["n_launch"]
+            per_launch_s, how = res["span_ms"] * 1e-3 / launches, "HIP events around the replayed graph / launches (boundaries included)"
+        bytes_per_launch = b_alg * n * steps / launches       # a rollout launch covers steps / launches steps (of <= 65 536 envs each)
         achieved = bytes_per_launch / per_launch_s / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None, "kernel": "k_step_hot" if path == "step" else "k_rollout_pc",
-                "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches}
+                "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
+                "steps_per_launch": steps / launches, "timing": how}
 
-    elapsed, dev_ms, n_fin, n_launch = measure(args.path, args.launch)
-    other = "rollout" if args.path == "step" else "step"
-    o_elapsed, o_dev_ms, _, o_launch = measure(other, args.launch) if args.also else (None, None, None, None)
+    out_bytes = 4 if args.out_dtype == "float32" else 8
+    tj = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:                                          # measured with rocprofv3 PMC passes on this workload (profiles/*_summary.md)
+            tj = json.load(open(tpath))
+        except Exception:
+            tj = {}
+
+    def traffic(path, layout, dtype, steps_per_launch):
+        """HBM bytes per launch from the committed rocprofv3 counter passes (NOT measured in this run): (bytes, source) or (None, None)."""
+        key = f"{path}_{layout}_{dtype}"
+        ent = tj.get(key)
+        if not ent or n != 65536:
+            return None, None
+        per = ent["bytes_per_step"] * steps_per_launch if path == "rollout" else ent["bytes_per_launch"]
+        return per, tj.get("source")
+
+    def leg(path, layout, dtype, steady=False):
+        res = measure(path, args.launch, layout, dtype, steady)
+        ob = 4 if dtype == "float32" else 8
+        roof = roofline(path, res, ob, K)
+        roof["traffic"], src = traffic(path, layout, dtype, roof["steps_per_launch"])
+        if src:
+            roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
+        name = (f"ptg_rollout, K steps fused ({res['n_launch']} kernel launch(es): <= 65536 envs x <= ~400 steps each)" if path == "rollout" else
+                f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})")
+        d = {"path": name, "obs_layout": layout, "obs_dtype": dtype, "value": n_total * K / res["elapsed"], "unit": "env-steps/s",
+             "ms_per_step": res["elapsed"] * 1e3 / K, "roofline": roof}
+        if res["steady"]:
+            us = res["steady"]["launch_us"]
+            b_alg = roof["algorithmic_bytes_per_env_step"]
+            t = float(np.sum(us)) * 1e-6                      # all launches covering the 400 steps (one per <= 65 536 envs)
+            d["steady_state"] = {"what": f"{STEADY_T}-step ptg_rollout after the timed region (stationary state mix), kernel-attached events",
+                                 "us_per_step": t * 1e6 / STEADY_T, "achieved": b_alg * n * STEADY_T / t / 1e9, "unit": "GB/s",
+                                 "frac": b_alg * n * STEADY_T / t / 1e9 / HBM_PEAK_GBPS, "env_steps_per_s_device": n * STEADY_T / t}
+        return d, res
+
+    head, res = leg(args.path, args.obs_layout, args.out_dtype, steady=args.steady)
+    also = {}
+    if args.also:
+        other = "rollout" if args.path == "step" else "step"
+        also[other + "_" + args.obs_layout] = leg(other, args.obs_layout, args.out_dtype)[0]
+        alt = "feature" if args.obs_layout != "feature" else "row"
+        also["rollout_" + alt] = leg("rollout", alt, args.out_dtype)[0]
 
     if rank == 0:
-        out_bytes = 4 if args.out_dtype == "float32" else 8
-        roof = roofline(args.path, dev_ms, out_bytes, n_launch)
-        tj = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and n == 65536 and args.out_dtype == "float32" and args.obs_layout == "feature":
-            try:                                      # measured with rocprofv3 PMC passes on this workload (profiles/*_summary.md)
-                tj = json.load(open(tpath))
-            except Exception:
-                tj = {}
-
-        n_launch_of = {args.path: n_launch, other: o_launch}
-
-        def traffic(path):                            # HBM bytes per launch, like `achieved`
-            if path == "step":
-                return tj.get("step_bytes_per_launch")
-            return tj["rollout_bytes_per_step"] * K / n_launch_of[path] if "rollout_bytes_per_step" in tj else None
-        roof["traffic"] = traffic(args.path)
         ppath = os.path.join(ROOT, "profiles", "hbm_probe_latest.json")
         if os.path.exists(ppath):                     # stream rates measured on this chip next to the vendor peak (SURVEY.md 8(d))
             try:
-                roof["measured_stream_GBps"] = {k: v for k, v in json.load(open(ppath)).items() if k != "source"}
+                pj = json.load(open(ppath))
+                head["roofline"]["measured_stream_GBps"] = dict({k: v for k, v in pj.items() if k != "source"},
+                                                                source=str(pj.get("source", "profiles/r01_hbm_probe.txt")) + " (not measured in this run)")
             except Exception:
                 pass
-        path_name = {"step": f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})",
-                     "rollout": f"ptg_rollout, K steps fused ({n_launch_of['rollout']} kernel launch(es): <= 65536 envs x <= ~400 steps each)"}
         line = {
             "metric": "env-steps/sec at N=65536 envs; achieved HBM GB/s vs roofline",
-            "value": n_total * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 observations / rewards" if args.out_dtype == "float32" else "f64 observations / rewards") +
+                     "; env state, reward coefficients and cum_rew in f64",
+            "data": "synthetic",
             "config": {"workload": f"N={n} envs/GPU, BS{args.scenario}/{args.operation}, synthetic 38-day trace (32-day episodes), "
                                    f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), noise: {args.noise}",
-                       "path": path_name[args.path], "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype,
-                       "obs_dim": F, "obs_layout": args.obs_layout, "parallelism": f"env-sharded x{world}, no per-step collective"},
-            "roofline": roof,
-            "finished_episodes_gathered": int(n_fin),
+                       "path": head["path"], "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype,
+                       "obs_dim": res["F"], "obs_layout": args.obs_layout, "parallelism": f"env-sharded x{world}, no per-step collective"},
+            "roofline": head["roofline"],
+            "finished_episodes_gathered": int(res["n_fin"]),
         }
-        if o_elapsed is not None:
-            line["also"] = {"path": path_name[other], "value": n_total * K / o_elapsed, "unit": "env-steps/s",
-                            "ms_per_step": o_elapsed * 1e3 / K, "roofline": dict(roofline(other, o_dev_ms, out_bytes, o_launch), traffic=traffic(other))}
+        if "steady_state" in head:
+            line["steady_state"] = head["steady_state"]
+        if also:
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PTG_ABI_VERSION 2   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT */
+#define PTG_ABI_VERSION 3   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile* */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -172,6 +172,14 @@ int ptg_rollout_info(ptg_env* env, const void* actions_dev, int action_kind, int
 /* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
  * per-launch timing); negative PTG_E_* on a bad argument. */
 int ptg_rollout_launches(ptg_env* env, int n_steps);
+/* Per-launch device time of the hot kernels (bench.py's roofline figure; no reference counterpart -- the reference times
+ * env.step with time.perf_counter at best).  ptg_profile(env, 1) starts a collection: every k_step_hot / k_rollout_pc launch
+ * from then on carries a (start, stop) HIP event pair stamped at the kernel's own begin and end (hipExtLaunchKernelGGL), i.e.
+ * what `rocprofv3 --kernel-trace` reports for the dispatch, without host launch latency in the interval.  ptg_profile(env, 0)
+ * stops it.  ptg_profile_read waits for the recorded launches, returns their durations in microseconds in launch order
+ * (count = min(launches, cap)) and clears the collection.  Launches being captured into a hipGraph must not be profiled. */
+int ptg_profile(ptg_env* env, int enable);
+int ptg_profile_read(ptg_env* env, double* us_host, int cap, int* count);
 /* hipStreamSynchronize(stream) + report an error a kernel flagged (PTG_E_ACTION / PTG_E_RANGE). */
 int ptg_sync(ptg_env* env, void* stream);
 

@@ -16,6 +16,7 @@
 #include "../../include/ptg_env.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -746,6 +747,7 @@ __global__ void k_build_fast(const DevParams P, const Rec* __restrict__ in, RecF
 // 1.55), a "broadcast" form that stores the 28 features a synchronised wave shares as 7 dwordx4, 32 / 16 envs per wave.
 template <typename T>
 __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) { return *(const T*)((const char*)base + byte_off); }
+typedef unsigned uv4 __attribute__((ext_vector_type(4)));
 // Output rows (observations, rewards, done flags) are written once and never read back by these kernels: non-temporal
 // stores keep the write stream from allocating in L2, where it evicts the window records and market series every step
 // re-reads (measured at N = 65 536: 2.86 -> 1.90 us per fused step, and the producer / consumer form 2.96 -> 1.51).
@@ -1168,6 +1170,42 @@ __device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4,
     M.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
 }
 
+// The table refresher.  The records and keys a step gathers are served from the XCD's L2 or the Infinity Cache as long as somebody
+// touched their lines recently -- true for a batch whose envs are spread over the tables, false for a SYNCHRONISED batch: after a
+// reset (or under a policy that drives every env alike) the envs walk through the tables as a front, every step gathers lines
+// nobody has touched since the output stream (9.8 MB per step at 65 536 envs) flushed them from the Infinity Cache, and each
+// of those misses goes to DRAM underneath a saturated write stream: measured 2.5 us per step instead of 1.5 for the first
+// ~270 steps after a reset (tools/fresh20.py, tools/phase_pmc.sh: same instruction counts, read latency + 40 %, TCP pending-line
+// stalls + 50 %; touching the tables right before a launch removes it).  k_refresh runs BESIDE k_rollout_pc, on a stream of its
+// own (one 64-lane workgroup per CU, no LDS, a handful of registers: it fits next to the rollout's workgroup): it re-reads its
+// 1 / gridDim share of the records and keys `passes` times, one pass per `period` ticks of the 100 MHz clock.  The loads are
+// inline asm into one never-read register quartet -- fire and forget.  It shares no vmcnt queue with the rollout's waves (an
+// in-order queue: a slow refresh load would hold back the gathers behind it; and a ninth wave inside the rollout's workgroup
+// caps the kernel at 168 registers, which spills), and it ends by itself after passes x period: no flag, no polling.
+__global__ void __launch_bounds__(64)
+k_refresh(const void* __restrict__ recf, const unsigned short* __restrict__ rkey, int n_rec, int passes, unsigned period)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned n16_rec = (unsigned)n_rec * 4u, n16 = n16_rec + ((unsigned)n_rec * 2u + 15u) / 16u;      // 16-byte pieces: records, then keys
+    const unsigned rows = (n16 + 63u) / 64u, per = (rows + gridDim.x - 1) / gridDim.x;                   // 1 KiB rows; this workgroup's share
+    const unsigned r_lo = min(rows, blockIdx.x * per), r_hi = min(rows, r_lo + per);
+    uv4 sink = {0u, 0u, 0u, 0u};
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int p = 0; p < passes; p++) {
+        for (unsigned row = r_lo; row < r_hi; row++) {
+            const unsigned g = min(row * 64u + lane, n16 - 1u);
+            const char* src = g < n16_rec ? (const char*)recf + (size_t)g * 16u : (const char*)rkey + (size_t)(g - n16_rec) * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src) : "memory");
+        }
+        if (p + 1 < passes) {                               // pace: the next pass starts (p + 1) periods after the first (the clock only runs forward)
+            const unsigned long long target = t0 + (unsigned long long)(p + 1) * period;
+            while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(sink));
+}
+
 template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL>
 __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
@@ -1175,9 +1213,10 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256): NP producer lanes, NP consumer lanes
+    const int nwork = blockDim.x;
     HotLds& L = *(HotLds*)s_dyn;
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
-    const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256)
     float* s_tiles = (float*)((unsigned char*)slot + 2 * sizeof(PcSlot));               // row-major: one [64][F] tile per consumer wave
     unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * RowTile<MOD, FLAT>::TILE * 4);   // [T][NP] decoded actions
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
@@ -1200,50 +1239,89 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         const int sh_np = __ffs(NP) - 1, total = T << sh_np;
         const int e_wg = e_base + blockIdx.x * NP;
         bool bad_any = false;           // flagged once after the loops: a ballot inside would keep them from unrolling
-        auto code_of = [&](int ri, float rf) -> int {
-            if (actk == PTG_ACT_F32) return decode_continuous(rf, 7);
-            const bool bad = (ri < -5) | (ri > 4);
-            bad_any |= bad;
-            return bad ? 7 : (ri < 0 ? ri + 5 : ri);
-        };
-        if (FULL && vec_rows) {          // four envs per lane: one dwordx4 (two for int64 actions) per quad, one packed LDS word
-#pragma unroll 16
-            for (int q4 = threadIdx.x; q4 < (total >> 2); q4 += blockDim.x) {
-                const int idx = q4 << 2, t = idx >> sh_np, x = idx & (NP - 1);
-                const size_t g = (size_t)t * P.N + e_wg + x;
-                int c[4];
-                if (actk == PTG_ACT_I64) {
-                    const longlong2 v0 = *(const longlong2*)((const long long*)actions + g), v1 = *(const longlong2*)((const long long*)actions + g + 2);
-                    const long long v[4] = {v0.x, v0.y, v1.x, v1.y};
+        // The element type is hoisted out of the loops (one instantiation per type): with the type test inside, every
+        // unrolled trip was its own basic block ending in `global_load; s_waitcnt vmcnt(0)` -- T / 8 serialised HBM round trips
+        // at the head of every launch.  Here each trip issues its four row loads back to back and decodes afterwards.
+        auto stage = [&](auto kind_tag) {
+            constexpr int AK = decltype(kind_tag)::value;
+            auto code_i = [&](int ri) -> int {
+                const bool bad = (ri < -5) | (ri > 4);
+                bad_any |= bad;
+                return bad ? 7 : (ri < 0 ? ri + 5 : ri);
+            };
+            auto pack = [&](const int* c) -> unsigned { return (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16) | ((unsigned)c[3] << 24); };
+            if (FULL && vec_rows) {      // four envs per lane: one dwordx4 (two for int64 actions) per quad, one packed LDS word
+                const int nq = total >> 2, bd = nwork;
+                for (int q0 = threadIdx.x; q0 < nq; q0 += 4 * bd) {
+                    if (AK == PTG_ACT_I64) {
+                        longlong2 v[4][2];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) c[j] = code_of((v[j] < -5 || v[j] > 4) ? 99 : (int)v[j], 0.f);
-                } else if (actk == PTG_ACT_F32) {
-                    const float4 v = *(const float4*)((const float*)actions + g);
-                    c[0] = code_of(0, v.x); c[1] = code_of(0, v.y); c[2] = code_of(0, v.z); c[3] = code_of(0, v.w);
-                } else {
-                    const int4 v = *(const int4*)((const int*)actions + g);
-                    c[0] = code_of(v.x, 0.f); c[1] = code_of(v.y, 0.f); c[2] = code_of(v.z, 0.f); c[3] = code_of(v.w, 0.f);
+                        for (int u = 0; u < 4; u++) {
+                            const int q = min(q0 + u * bd, nq - 1), idx = q << 2, t = idx >> sh_np, x = idx & (NP - 1);
+                            const long long* src = (const long long*)actions + ((size_t)t * P.N + e_wg + x);
+                            v[u][0] = *(const longlong2*)src; v[u][1] = *(const longlong2*)(src + 2);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int q = q0 + u * bd;
+                            const long long w[4] = {v[u][0].x, v[u][0].y, v[u][1].x, v[u][1].y};
+                            int c[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) c[j] = code_i((w[j] < -5 || w[j] > 4) ? 99 : (int)w[j]);
+                            if (q < nq) *(unsigned*)(s_act + (q << 2)) = pack(c);
+                        }
+                    } else {
+                        int4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int q = min(q0 + u * bd, nq - 1), idx = q << 2, t = idx >> sh_np, x = idx & (NP - 1);
+                            v[u] = *(const int4*)((const int*)actions + ((size_t)t * P.N + e_wg + x));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int q = q0 + u * bd;
+                            int c[4];
+                            if (AK == PTG_ACT_F32) {
+                                c[0] = decode_continuous(__int_as_float(v[u].x), 7); c[1] = decode_continuous(__int_as_float(v[u].y), 7);
+                                c[2] = decode_continuous(__int_as_float(v[u].z), 7); c[3] = decode_continuous(__int_as_float(v[u].w), 7);
+                            } else {
+                                c[0] = code_i(v[u].x); c[1] = code_i(v[u].y); c[2] = code_i(v[u].z); c[3] = code_i(v[u].w);
+                            }
+                            if (q < nq) *(unsigned*)(s_act + (q << 2)) = pack(c);
+                        }
+                    }
                 }
-                *(unsigned*)(s_act + idx) = (unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16) | ((unsigned)c[3] << 24);
+            } else {
+#pragma unroll 4
+                for (int idx = threadIdx.x; idx < total; idx += nwork) {
+                    const int t = idx >> sh_np, x = idx & (NP - 1);
+                    const int eg = min(e_wg + x, P.N - 1);
+                    const size_t g = (size_t)t * P.N + eg;
+                    int code;
+                    if (AK == PTG_ACT_F32) code = decode_continuous(((const float*)actions)[g], 7);
+                    else if (AK == PTG_ACT_I64) { const long long w = ((const long long*)actions)[g]; code = code_i((w < -5 || w > 4) ? 99 : (int)w); }
+                    else code = code_i(((const int*)actions)[g]);
+                    s_act[idx] = (unsigned char)code;
+                }
             }
-        } else {
-#pragma unroll 8
-            for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-                const int t = idx >> sh_np, x = idx & (NP - 1);
-                const int eg = min(e_wg + x, P.N - 1);
-                int ri = 0; float rf = 0.f;
-                hot_fetch(actk, actions, (size_t)t * P.N + eg, ri, rf);
-                s_act[idx] = (unsigned char)code_of(ri, rf);
-            }
-        }
+        };
+        if (actk == PTG_ACT_F32) stage(std::integral_constant<int, PTG_ACT_F32>{});
+        else if (actk == PTG_ACT_I64) stage(std::integral_constant<int, PTG_ACT_I64>{});
+        else stage(std::integral_constant<int, PTG_ACT_I32>{});
         if (__ballot(bad_any)) { if (bad_any) atomicOr(P.err, 1); }
     }
     hot_stage_lds(P, L);
-    if (LDSLUT) {
-        const int words = (N_DEST * P.nT + 1) / 2;
-        const unsigned* src = (const unsigned*)lut16;
-        unsigned* dst = (unsigned*)s_lut;
-        for (int q = threadIdx.x; q < words; q += blockDim.x) dst[q] = src[q];
+    if (LDSLUT) {                       // 16-byte pieces, four loads in flight per lane (the lookup is padded to whole pieces)
+        const int n16 = (N_DEST * P.nT * 2 + 15) / 16, bd = nwork;
+        const uint4* src = (const uint4*)lut16;
+        uint4* dst = (uint4*)s_lut;
+        for (int q0 = threadIdx.x; q0 < n16; q0 += 4 * bd) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = src[min(q0 + u * bd, n16 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int q = q0 + u * bd; if (q < n16) dst[q] = v[u]; }
+        }
     }
     __syncthreads();
     const unsigned short* lut = LDSLUT ? s_lut : nullptr;
@@ -1548,6 +1626,14 @@ struct ptg_env {
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
     int* d_eps_ind = nullptr;
+    // experiment knobs, read from the environment ONCE in ptg_create (PTG_NO_HOT_KERNELS, PTG_NO_LDS_LUT, PTG_NO_REFRESH, PTG_REFRESH_ALWAYS, PTG_PC_CHUNK, PTG_BLOCK)
+    bool knob_no_hot = false, knob_no_lds_lut = false, knob_no_refresh = false, knob_refresh_always = false;
+    int front_horizon = 0;       // steps after a synchronised reset during which the table refresher keeps rolling (k_refresh)
+    hipStream_t ref_stream = nullptr;
+    int knob_chunk = 65536, knob_block = 0;
+    // per-launch timing (ptg_profile): kernel-attached start / stop events of the launches since profiling was switched on
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_used, prof_free;
     std::string err;
 };
 
@@ -1602,6 +1688,19 @@ int launch_check(ptg_env* h, const char* what)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(h, PTG_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
     return 0;
+}
+
+// ptg_profile: a (start, stop) event pair attached to the next kernel launch (hipExtLaunchKernelGGL stamps them at the kernel's
+// own begin / end, like the profiler's dispatch timestamps: no host launch latency inside the interval); nulls when off
+void prof_pair(ptg_env* h, hipEvent_t& e0, hipEvent_t& e1)
+{
+    e0 = e1 = nullptr;
+    if (!h->profiling) return;
+    std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
+    if (!h->prof_free.empty()) { p = h->prof_free.back(); h->prof_free.pop_back(); }
+    else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return;
+    h->prof_used.push_back(p);
+    e0 = p.first; e1 = p.second;
 }
 
 int build_tables(ptg_env* h, const ptg_tables* tb)
@@ -1686,7 +1785,7 @@ int build_tables(ptg_env* h, const ptg_tables* tb)
         bool fits = true;
         for (int v : lut) fits = fits && v >= 0 && v < 65536;
         if (fits) {
-            std::vector<unsigned short> l16(lut.size() + 2, 0);
+            std::vector<unsigned short> l16((lut.size() + 15) / 8 * 8, 0);      // whole 16-byte pieces (k_rollout_pc stages it as uint4)
             for (size_t q = 0; q < lut.size(); q++) l16[q] = (unsigned short)lut[q];
             if ((rc = dev_upload(h, &h->d_lut16, l16.data(), l16.size()))) return rc;
         }
@@ -1782,18 +1881,23 @@ HotParams make_hot_params(const ptg_env* h)
 // the hot kernels apply to float32 outputs, 13-hour look-ahead, a synchronised batch, and steps on which no env terminates
 bool hot_eligible(const ptg_env* h)
 {
-    return h->cfg.out_dtype == PTG_OUT_F32 && h->cfg.price_ahead == 13 && h->sync_k >= 0 && !getenv("PTG_NO_HOT_KERNELS") &&
+    return h->cfg.out_dtype == PTG_OUT_F32 && h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot &&
            (unsigned long long)h->n * h->F * 4ull < 0xFFFFFFFFull;
 }
 
 int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
 
 template <int LAY, bool MOD, int NOISE>
-void launch_step_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, float* obs, float* rew, uint8_t* done)
+void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, float* obs, float* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
     const dim3 grid(grid_for(h->n, 256)), block(256);
-    hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
+    if (h->profiling) {
+        hipEvent_t e0, e1;
+        prof_pair(h, e0, e1);
+        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, h->sync_k, obs, rew, done);
+    } else
+        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
 }
 
 // Launch geometry of the fused hot rollout.  One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many
@@ -1804,25 +1908,45 @@ struct PcPlan { int chunk, block, t_cap; bool lds_lut; size_t fixed, lut_bytes, 
 PcPlan pc_plan(const ptg_env* h)
 {
     PcPlan pl;
-    pl.chunk = getenv("PTG_PC_CHUNK") ? atoi(getenv("PTG_PC_CHUNK")) : 65536;
-    pl.chunk = std::max(256, pl.chunk / 256 * 256);
+    pl.chunk = std::max(256, h->knob_chunk / 256 * 256);
     pl.fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);     // + the row-major tiles, below
-    pl.lut_bytes = 4 * (((size_t)N_DEST * h->Tvals.size() + 1) / 2);
+    pl.lut_bytes = 16 * (((size_t)N_DEST * h->Tvals.size() * 2 + 15) / 16);
     pl.lds_max = 160 * 1024 - 512;
     pl.block = 128;                                         // half producers, half consumers; >= 256 workgroups when possible
     while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block) >= 256) pl.block *= 2;     // block/2 envs per workgroup
-    if (getenv("PTG_BLOCK")) pl.block = atoi(getenv("PTG_BLOCK"));
+    if (h->knob_block) pl.block = h->knob_block;
     const int np = pl.block / 2;
     if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F) * 4;      // one [64][pitch] float tile per consumer wave (RowTile::PITCH)
     // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
-    pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !getenv("PTG_NO_LDS_LUT");
+    pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !h->knob_no_lds_lut;
     const size_t avail = pl.lds_max - pl.fixed - (pl.lds_lut ? pl.lut_bytes : 0) - 64;
     pl.t_cap = (int)std::min<size_t>(512, avail / np);
     return pl;
 }
 
+// k_refresh beside a hot rollout launch of m envs x tn steps that starts at step count k0 (see k_refresh).  One pass over the
+// tables per ~192 MB of output (the Infinity Cache holds 256 MB).  The rolling passes only while a synchronised batch is still
+// walking the tables as a front (the first front_horizon steps of an episode; PTG_REFRESH_ALWAYS: a policy that keeps the envs in
+// lock-step): afterwards the envs' own gathers keep every line warm, and one pass at the head of the launch covers whatever
+// other work evicted meanwhile.  Not while `st` is being captured into a graph (the refresher would run at capture time).
+void launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
+{
+    if (h->knob_no_refresh || !h->ref_stream) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    const double step_bytes = (double)m * (h->F * 4 + 5);
+    const double pass_steps = std::max(8.0, 192e6 / step_bytes);
+    const bool roll = h->knob_refresh_always || k0 < h->front_horizon;
+    const int passes = roll ? std::max(1, (int)std::ceil(tn / pass_steps)) : 1;
+    const double step_us = std::max(0.9, step_bytes / 6.2e6);                 // the rollout's pace: its output stream at ~6.2 TB/s, >= the producers' chain
+    const unsigned period = (unsigned)std::min(4.0e6, pass_steps * step_us * 100.0);      // ticks of the 100 MHz clock; <= 40 ms
+    const long long n16 = (long long)h->rec_total * 4 + ((long long)h->rec_total * 2 + 15) / 16;
+    const int grid = (int)std::min<long long>(256, (n16 + 63) / 64);
+    hipLaunchKernelGGL(k_refresh, dim3(grid), dim3(64), 0, h->ref_stream, (const void*)h->P.recf, (const unsigned short*)h->d_rkey, (int)h->rec_total, passes, period);
+}
+
 template <int LAY, bool MOD, int NOISE>
-void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
+void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
     const PcPlan pl = pc_plan(h);
@@ -1843,11 +1967,19 @@ void launch_rollout_hot(const ptg_env* h, hipStream_t st, const void* actions, i
             const int m = std::min(chunk, h->n - e0);
             const dim3 grid(grid_for(m, np)), block(bs_all);
             const bool full = m % np == 0;
+            launch_refresher(h, st, m, tn, k0);
 #define PTG_PC2(LL, FULL)                                                                                             \
     do {                                                                                                              \
         auto kfn = k_rollout_pc<LAY, MOD, NOISE, LL, FULL>;                                                           \
-        if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); \
-        hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
+        static int attr_dev = -1;      /* > 64 KiB of dynamic LDS needs the attribute: once per instantiation and device */ \
+        if (attr_dev != h->device) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_dev = h->device; } \
+        if (h->profiling) {                                                                                           \
+            hipEvent_t pe0, pe1;                                                                                      \
+            prof_pair(h, pe0, pe1);                                                                                   \
+            hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)sh, st, pe0, pe1, 0, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, \
+                                  (const unsigned short*)h->d_lut16, (const unsigned short*)h->d_rkey, e0, vec_rows); \
+        } else                                                                                                        \
+            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
     } while (0)
 #define PTG_PC(LL) do { if (full) PTG_PC2(LL, true); else PTG_PC2(LL, false); } while (0)
             if (ll) PTG_PC(true); else PTG_PC(false);
@@ -1908,6 +2040,9 @@ void ptg_destroy(ptg_env* env)
     if (env->vn_partials) (void)hipFree(env->vn_partials);
     if (env->vn_den) (void)hipFree(env->vn_den);
     if (env->vn_moments) (void)hipFree(env->vn_moments);
+    if (env->ref_stream) { (void)hipStreamSynchronize(env->ref_stream); (void)hipStreamDestroy(env->ref_stream); }
+    for (auto* v : {&env->prof_used, &env->prof_free})
+        for (auto& p : *v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete env;
 }
 
@@ -1931,6 +2066,10 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
 
     ptg_env* h = new ptg_env();
     h->cfg = *cfg; h->n = n_envs; h->device = device_id; h->n_sets = n_sets;
+    h->knob_no_hot = getenv("PTG_NO_HOT_KERNELS") != nullptr; h->knob_no_lds_lut = getenv("PTG_NO_LDS_LUT") != nullptr;
+    h->knob_no_refresh = getenv("PTG_NO_REFRESH") != nullptr; h->knob_refresh_always = getenv("PTG_REFRESH_ALWAYS") != nullptr;
+    if (const char* v = getenv("PTG_PC_CHUNK")) h->knob_chunk = atoi(v);
+    if (const char* v = getenv("PTG_BLOCK")) { const int b = atoi(v); if (b == 128 || b == 256 || b == 512) h->knob_block = b; }
     h->S = (int)((double)cfg->sim_step / (double)cfg->time_step_op);     // :66
     h->F = cfg->raw_modified ? 2 * cfg->price_ahead + 9 : cfg->price_ahead + 4 + 9;
     h->fast = (cfg->out_dtype == PTG_OUT_F32);          // float32 outputs without info rows run the strength-reduced kernels
@@ -1941,6 +2080,12 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     auto fail = [&](int code) { g_create_err = h->err; ptg_destroy(h); return code; };
     if (h->S < 1) { set_err(h, PTG_E_INVALID, "step_size < 1"); return fail(PTG_E_INVALID); }
     if ((rc = build_tables(h, tables))) return fail(rc);
+    {   // mixing time of a synchronised batch, in steps: twice the longest table's walk plus a margin (measured at sim_step 600:
+        // the slow phase ends 265-285 steps after a reset; this gives 364)
+        int longest = 0;
+        for (int t = 0; t < NT; t++) longest = std::max(longest, h->tab_rows[t]);
+        h->front_horizon = 2 * ((longest + h->S - 1) / h->S) + 64;
+    }
     if ((rc = build_market(h, sets, n_sets))) return fail(rc);
 
     if (cfg->obs_layout == PTG_OBS_SB3_FLAT) {            // rows in SB3's flattened form: sub-spaces by sorted key, METH_STATUS one-hot
@@ -2049,6 +2194,11 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     }
     hipLaunchKernelGGL(k_init_state, dim3(grid_for(n_envs, 256)), dim3(256), 0, 0, P, 0, 0);
     if ((rc = launch_check(h, "k_init_state"))) return fail(rc);
+    if (!h->knob_no_refresh) {                              // the refresher's own stream: highest priority, never blocks on the NULL stream
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->ref_stream, hipStreamNonBlocking, hi) != hipSuccess) { h->ref_stream = nullptr; (void)hipGetLastError(); }
+    }
     if (hipDeviceSynchronize() != hipSuccess) { set_err(h, PTG_E_HIP, "device synchronize failed after init"); return fail(PTG_E_HIP); }
     *out = h;
     return 0;
@@ -2418,6 +2568,35 @@ int ptg_vn_set(ptg_env* h, const double* stats3_host, const double* returns_host
     HIP_TRY(h, hipDeviceSynchronize());
     if (stats3_host) HIP_TRY(h, hipMemcpy(h->vn_stats, stats3_host, sizeof(double) * 3, hipMemcpyHostToDevice));
     if (returns_host) HIP_TRY(h, hipMemcpy(h->vn_returns, returns_host, sizeof(double) * h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ptg_profile(ptg_env* h, int enable)
+{
+    if (!h) return PTG_E_INVALID;
+    if (enable && !h->profiling) {                          // a fresh collection
+        for (auto& p : h->prof_used) h->prof_free.push_back(p);
+        h->prof_used.clear();
+    }
+    h->profiling = enable != 0;
+    return 0;
+}
+
+int ptg_profile_read(ptg_env* h, double* us_host, int cap, int* count)
+{
+    if (!h || !count || cap < 0 || (cap > 0 && !us_host)) return set_err(h, PTG_E_INVALID, "ptg_profile_read: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int n = 0;
+    for (auto& p : h->prof_used) {
+        HIP_TRY(h, hipEventSynchronize(p.second));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, p.first, p.second));
+        if (n < cap) us_host[n] = (double)ms * 1e3;
+        n++;
+        h->prof_free.push_back(p);
+    }
+    h->prof_used.clear();
+    *count = std::min(n, cap);
     return 0;
 }
 

@@ -246,6 +246,17 @@ class HipEngine:
             self._chk(k)
         return k
 
+    def profile(self, enable=True):
+        """Start / stop collecting the device time of every hot-kernel launch (kernel-attached HIP events)."""
+        self._chk(self._L.ptg_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, cap=65536):
+        """Durations [us] of the launches recorded since profile(True), in launch order; waits for them and clears the list."""
+        out = np.zeros(cap)
+        cnt = C.c_int(0)
+        self._chk(self._L.ptg_profile_read(self._h, _dp(out), cap, C.byref(cnt)))
+        return out[:cnt.value].copy()
+
     def sync(self):
         self._chk(self._L.ptg_sync(self._h, self._stream()))
 

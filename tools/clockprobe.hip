@@ -1,0 +1,66 @@
+// clockprobe.hip -- diagnostic helpers for tools/coldstart.py (NOT part of the product library).
+//   clk_probe   one 64-lane workgroup per CU spins for `spin_cycles` shader cycles and records (s_memtime, s_memrealtime)
+//               before and after: shader clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+//   bw_write    a pure write stream (dwordx4 per lane, non-temporal) over `bytes`;  bw_read  a pure dwordx4 read stream.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/libclockprobe.so tools/clockprobe.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace {
+
+__global__ void __launch_bounds__(64) k_clk(unsigned long long* out, int spin_cycles)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = t0;
+    while ((long long)(t1 - t0) < (long long)spin_cycles) {
+        __builtin_amdgcn_s_sleep(2);
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 4 + 0] = t0; out[blockIdx.x * 4 + 1] = t1;
+        out[blockIdx.x * 4 + 2] = r0; out[blockIdx.x * 4 + 3] = r1;
+    }
+}
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_write(vf4* p, size_t n4, float v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const vf4 x = {v, v, v, v};
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) __builtin_nontemporal_store(x, p + g);
+}
+
+__global__ void __launch_bounds__(256) k_read(const vf4* p, size_t n4, float* sink)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    vf4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) acc += __builtin_nontemporal_load(p + g);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clk_probe(void* stream, unsigned long long* out_dev, int n_wg, int spin_cycles)
+{
+    hipLaunchKernelGGL(k_clk, dim3(n_wg), dim3(64), 0, (hipStream_t)stream, out_dev, spin_cycles);
+    return (int)hipGetLastError();
+}
+
+int bw_write(void* stream, void* buf, size_t bytes)
+{
+    hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, (hipStream_t)stream, (vf4*)buf, bytes / 16, 1.0f);
+    return (int)hipGetLastError();
+}
+
+int bw_read(void* stream, const void* buf, size_t bytes, float* sink)
+{
+    hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const vf4*)buf, bytes / 16, sink);
+    return (int)hipGetLastError();
+}
+
+}

@@ -3,16 +3,23 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
 tag = sys.argv[1]
+bench_args = sys.argv[2] if len(sys.argv) > 2 else "--gpus 1 --steps 20 --warmup 5"
+K = int(re.search(r"--steps (\d+)", bench_args).group(1)) if "--steps" in bench_args else 2000
 os.makedirs("profiles", exist_ok=True)
-ours = ("k_step", "k_rollout", "k_reset", "k_build", "k_fill", "k_init", "k_zero", "k_extract")
+ours = ("k_step", "k_rollout", "k_reset", "k_build", "k_fill", "k_init", "k_zero", "k_extract", "k_refresh", "k_vn")
+LAY = {"0": "row", "1": "feature", "2": "sb3_flat"}
 
 
 def short(name):
-    for k in ("k_step_hot", "k_rollout_pc", "k_extract_keys", "k_step", "k_rollout", "k_reset", "k_build_records", "k_build_argmin", "k_build_fast", "k_fill_noise", "k_init_state", "k_zero_noise_count"):
+    m = re.search(r"(k_rollout_pc|k_step_hot)<(\d)", name)
+    if m:
+        return f"{m.group(1)}<{LAY[m.group(2)]}>"
+    for k in ("k_refresh", "k_extract_keys", "k_step", "k_reset", "k_build_records", "k_build_argmin", "k_build_fast", "k_fill_noise", "k_init_state", "k_zero_noise_count"):
         if k in name:
             return k
     return name[:60]
@@ -37,48 +44,59 @@ for f in glob.glob(f"gpurun_out/prof_{tag}_trace/**/*kernel_trace.csv", recursiv
         trace[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         meta[k] = {x: r[x] for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
 
-pmc = defaultdict(lambda: defaultdict(list))
+pmc = defaultdict(lambda: defaultdict(list))          # kernel -> counter -> [(dispatch id, value)]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/prof_{tag}_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 
 lines = [f"# rocprofv3 summary, {tag}", "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (defaults: 400 warm-up + 2000 timed steps of both",
-         "paths: the k_rollout_pc dispatches are the 400-step warm-up launch and the timed rollout's 401 + 401 + 401 + 401 + 396-step launches",
-         "(400 steps per launch on average, as in bench.py's avg_launch_us); every k_step_hot dispatch is one vector step; 1x MI355X, N = 65536 envs,",
-         "BS1/OP1, float32 feature-major obs, in-kernel RNG).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of",
-         "`bench.py --steps 100 --warmup 10 --launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads);",
-         "counter unit KiB.", "",
-         "| kernel | dispatches | avg us | min us | max us | VGPR | SGPR | LDS B | block | grid |", "|---|---|---|---|---|---|---|---|---|---|"]
+         f"Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py {bench_args} --no-cpu-baseline` (1x MI355X, N = 65536 envs, BS1/OP1, float32,",
+         "in-kernel RNG).  bench.py runs three legs, each on a fresh handle: the headline `ptg_rollout` with row-major observations, `ptg_step`",
+         "(K launches replayed as one hipGraph) and `ptg_rollout` with feature-major observations.  Dispatches of `k_rollout_pc<row>` in trace order:",
+         f"the W-step warm-up launch from reset, THE TIMED {K}-step LAUNCH (bench.py's `roofline.avg_launch_us`), then the two 400-step",
+         "steady-state launches (`steady_state`); `k_rollout_pc<feature>`: warm-up, timed.  `k_refresh` is the table refresher that runs beside",
+         "every rollout launch on its own stream (DESIGN.md section 5).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the",
+         "same command with `--launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads); counter unit KiB.", "",
+         "| kernel | dispatches | avg us | min us | max us | VGPR | SGPR | LDS B | scratch | block | grid |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 for k in sorted(trace, key=lambda x: -sum(v[1] for v in trace[x])):
     if not any(k.startswith(o) for o in ours):
         continue
     d, m = [x[1] for x in sorted(trace[k])], meta[k]
-    lines.append(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {min(d) / 1e3:.2f} | {max(d) / 1e3:.2f} | {m['VGPR_Count']} | {m['SGPR_Count']} | {m['LDS_Block_Size']} | {m['Workgroup_Size_X']} | {m['Grid_Size_X']} |")
-    if k == "k_rollout_pc" and len(d) > 1:
-        timed = d[1:]                                     # trace order: the first dispatch is the warm-up launch from reset
-        note = (f"`k_rollout_pc`: the {len(timed)} dispatches of the timed rollout average {sum(timed) / len(timed) / 1e3:.2f} us "
-                f"(bench.py's `roofline.avg_launch_us`, same launches without the profiler: 606-620 us); the warm-up launch from reset took {d[0] / 1e3:.2f} us.")
-traffic = {}
-if "note" in dir():
-    lines += ["", note]
-lines += ["", "| kernel | FETCH_SIZE KiB/launch (raw) | read bytes/launch (x2 corrected) | WRITE_SIZE KiB/launch | HBM bytes/launch |", "|---|---|---|---|---|"]
-for k in ("k_step_hot", "k_rollout_pc"):
-    if k in pmc:
-        fs = pmc[k].get("FETCH_SIZE", [])
-        ws = pmc[k].get("WRITE_SIZE", [])
-        # rollout: the 10-step warm-up launch and the 100-step launch differ; use the largest (the timed launch)
-        f = max(fs) if fs else None
-        w_ = max(ws) if ws else None
-        tot = (2 * f * 1024 if f else 0) + (w_ * 1024 if w_ else 0)
-        lines.append(f"| {k} | {f} | {2 * f * 1024 if f else None} | {w_} | {tot} |")
-        traffic[("step" if k == "k_step_hot" else "rollout") + "_bytes_per_launch"] = tot
-        traffic[("step" if k == "k_step_hot" else "rollout") + "_pmc_launch_steps"] = 1 if k == "k_step_hot" else 100
+    lines.append(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {min(d) / 1e3:.2f} | {max(d) / 1e3:.2f} | {m['VGPR_Count']} | {m['SGPR_Count']} | {m['LDS_Block_Size']} | {m['Scratch_Size']} | {m['Workgroup_Size_X']} | {m['Grid_Size_X']} |")
+lines.append("")
+for k in sorted(trace):
+    if k.startswith("k_rollout_pc"):
+        d = [x[1] for x in sorted(trace[k])]
+        lines.append(f"`{k}` dispatches in order [us]: " + ", ".join(f"{x / 1e3:.1f}" for x in d) +
+                     (f"  -> timed {K}-step launch: **{d[1] / 1e3:.1f} us** = {d[1] / 1e3 / K:.3f} us per step" if len(d) > 1 else "") +
+                     (f"; second 400-step steady rollout: {sum(d[2 + (len(d) - 2) // 2:]) / 1e3:.1f} us = {sum(d[2 + (len(d) - 2) // 2:]) / 1e3 / 400:.3f} us per step" if len(d) > 3 else ""))
+traffic = {"source": f"profiles/{tag}_summary.md"}
+lines += ["", "| kernel | dispatch | FETCH_SIZE KiB (raw) | read bytes (x2 corrected) | WRITE_SIZE KiB | HBM bytes | per step / launch |", "|---|---|---|---|---|---|---|"]
+for k in sorted(pmc):
+    if not (k.startswith("k_rollout_pc") or k.startswith("k_step_hot")):
+        continue
+    fs = [v for _, v in sorted(pmc[k].get("FETCH_SIZE", []))]
+    ws = [v for _, v in sorted(pmc[k].get("WRITE_SIZE", []))]
+    layout = k[k.index("<") + 1:-1]
+    if k.startswith("k_rollout_pc") and len(fs) > 1 and len(ws) > 1:
+        f, w_ = fs[1], ws[1]                                  # the timed launch (trace order: warm-up, timed, ...)
+        tot = 2 * f * 1024 + w_ * 1024
+        lines.append(f"| {k} | timed {K}-step launch | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / K:.0f} B per step = {tot / K / 65536:.1f} B per env-step |")
+        traffic[f"rollout_{layout}_float32"] = {"bytes_per_step": tot / K, "steps_in_measured_launch": K}
+        if len(fs) > 3 and len(ws) > 3 and len(fs) == len(ws):      # the two 400-step steady-state rollouts (each one or more launches): the second one
+            h2 = (len(fs) - 2) // 2
+            f, w_ = sum(fs[2 + h2:]), sum(ws[2 + h2:])
+            tot = 2 * f * 1024 + w_ * 1024
+            lines.append(f"| {k} | second 400-step steady rollout ({h2} launch(es)) | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / 400:.0f} B per step = {tot / 400 / 65536:.1f} B per env-step |")
+            traffic[f"rollout_{layout}_float32_steady"] = {"bytes_per_step": tot / 400, "steps_in_measured_launch": 400}
+    elif k.startswith("k_step_hot") and fs and ws:
+        f, w_ = sum(fs) / len(fs), sum(ws) / len(ws)
+        tot = 2 * f * 1024 + w_ * 1024
+        lines.append(f"| {k} | average of {len(fs)} launches | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / 65536:.1f} B per env-step |")
+        traffic[f"step_{layout}_float32"] = {"bytes_per_launch": tot}
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
-if "rollout_bytes_per_launch" in traffic and "step_bytes_per_launch" in traffic:      # what bench.py reports as roofline.traffic
-    json.dump({"source": f"profiles/{tag}_summary.md", "step_bytes_per_launch": traffic["step_bytes_per_launch"],
-               "rollout_bytes_per_step": traffic["rollout_bytes_per_launch"] / traffic["rollout_pmc_launch_steps"]},
-              open("profiles/traffic_latest.json", "w"), indent=1)
+if len(traffic) > 1:                                          # what bench.py reports as roofline.traffic
+    json.dump(traffic, open("profiles/traffic_latest.json", "w"), indent=1)
 print("\n".join(lines))
