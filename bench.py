@@ -312,6 +312,8 @@ def main():
         also[other + "_" + args.obs_layout] = leg(other, args.obs_layout, args.out_dtype)[0]
         alt = "feature" if args.obs_layout != "feature" else "row"
         also["rollout_" + alt] = leg("rollout", alt, args.out_dtype)[0]
+        if args.out_dtype == "float32":                   # the reference's declared dtype (env/ptg_gym_env.py:166-202): float64 observations / rewards
+            also["rollout_" + args.obs_layout + "_float64"] = leg("rollout", args.obs_layout, "float64")[0]
 
     if rank == 0:
         ppath = os.path.join(ROOT, "profiles", "hbm_probe_latest.json")

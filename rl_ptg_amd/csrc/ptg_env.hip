@@ -489,6 +489,46 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, int e, co
     }
 }
 
+// Reward of one step (:280-334) from the window means and the three prices, operand order of the reference.  C = DevParams or RewC
+// (same field names): the generic kernels and the float64 hot kernels share this one expression tree, hence identical bits.
+struct RewTerms { double ch4_rev, steam_rev, o2_rev, eua_rev, chp_rev, cost_heat, cost_elz, cost_water, rew; };
+template <class C>
+__device__ __forceinline__ RewTerms reward_ref(const C& P, double H2, double CH4, double H2r, double H2O, double heat, double el, double gas,
+                                               double eua, double b_s3)
+{
+    RewTerms t;
+    const double ch4_vol = CH4 * P.c_mol;
+    const double h2r_vol = H2r * P.c_mol;
+    const double Q_ch4 = ch4_vol * P.Hu_ch4 * 1000;
+    const double Q_h2r = h2r_vol * P.Hu_h2 * 1000;
+    t.ch4_rev = (Q_ch4 + Q_h2r) * gas;
+    const double power_chp = Q_ch4 * P.eta_chp * b_s3;
+    const double Q_chp = Q_ch4 * P.one_m_eta_chp * b_s3;
+    t.chp_rev = power_chp * P.eeg;
+    const double Q_steam = H2O * P.dt_cp_evap / 3600;
+    t.steam_rev = (Q_steam + Q_chp) * P.heat_price;
+    const double h2_vol = H2 * P.c_mol;
+    const double o2_vol = 0.5 * h2_vol * 3600;
+    t.o2_rev = o2_vol * P.o2_price;
+    const double co2 = CH4 * P.M_co2 / 1000;
+    t.eua_rev = co2 / 1000 * 3600 * eua * 100;
+    t.cost_heat = heat / 1000 * el;
+    const double load = h2_vol / P.max_h2;
+    double eta;
+    if (load < P.min_load) {
+        eta = 0.02;
+    } else {
+        const double l2 = load * load, inv = 1.0 / load;
+        eta = 0.598 - 0.325 * l2 + 0.218 * (l2 * load) + 0.01 * inv - P.c_m2 * (inv * inv) + P.c_m3 * (inv * inv * inv);
+    }
+    t.cost_elz = h2_vol * P.Hu_h2 * 1000 / eta * el;
+    const double cost_el = t.cost_heat + t.cost_elz;
+    const double water_elz = H2 * P.M_h2o / 1000 * 3600;
+    t.cost_water = (H2O + water_elz) / P.rho * P.water_price;
+    t.rew = (t.ch4_rev + t.chp_rev + t.steam_rev + t.eua_rev + t.o2_rev - cost_el - t.cost_water) * P.sim_step_d / 3600;
+    return t;
+}
+
 // One env step.  Returns terminated.
 template <typename OUT, bool FAST, bool INFO, bool FM, int PAC, class LUT>
 __device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta, const LUT& lut, Regs& R, int e, int act,
@@ -535,36 +575,10 @@ __device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta
         R.a.flags = (R.a.flags & 0x1FFFFu) | ((unsigned)rec.tkey << 17);
         const double2 sc = P.sincos[kk];
         const double H2 = rec.m[0], CH4 = rec.m[1], H2r = rec.m[2], H2O = rec.m[3], heat = rec.m[4];
-        // :280-334 reward, operand order of the reference
-        const double ch4_vol = CH4 * P.c_mol;
-        const double h2r_vol = H2r * P.c_mol;
-        const double Q_ch4 = ch4_vol * P.Hu_ch4 * 1000;
-        const double Q_h2r = h2r_vol * P.Hu_h2 * 1000;
-        const double ch4_rev = (Q_ch4 + Q_h2r) * gas;
-        const double power_chp = Q_ch4 * P.eta_chp * setc.x;
-        const double Q_chp = Q_ch4 * P.one_m_eta_chp * setc.x;
-        const double chp_rev = power_chp * P.eeg;
-        const double Q_steam = H2O * P.dt_cp_evap / 3600;
-        const double steam_rev = (Q_steam + Q_chp) * P.heat_price;
-        const double h2_vol = H2 * P.c_mol;
-        const double o2_vol = 0.5 * h2_vol * 3600;
-        const double o2_rev = o2_vol * P.o2_price;
-        const double co2 = CH4 * P.M_co2 / 1000;
-        const double eua_rev = co2 / 1000 * 3600 * eua * 100;
-        const double cost_heat = heat / 1000 * el;
-        const double load = h2_vol / P.max_h2;
-        double eta;
-        if (load < P.min_load) {
-            eta = 0.02;
-        } else {
-            const double l2 = load * load, inv = 1.0 / load;
-            eta = 0.598 - 0.325 * l2 + 0.218 * (l2 * load) + 0.01 * inv - P.c_m2 * (inv * inv) + P.c_m3 * (inv * inv * inv);
-        }
-        const double cost_elz = h2_vol * P.Hu_h2 * 1000 / eta * el;
-        const double cost_el = cost_heat + cost_elz;
-        const double water_elz = H2 * P.M_h2o / 1000 * 3600;
-        const double cost_water = (H2O + water_elz) / P.rho * P.water_price;
-        rew = (ch4_rev + chp_rev + steam_rev + eua_rev + o2_rev - cost_el - cost_water) * P.sim_step_d / 3600;
+        const RewTerms rt = reward_ref(P, H2, CH4, H2r, H2O, heat, el, gas, eua, setc.x);
+        const double ch4_rev = rt.ch4_rev, steam_rev = rt.steam_rev, o2_rev = rt.o2_rev, eua_rev = rt.eua_rev, chp_rev = rt.chp_rev,
+                     cost_heat = rt.cost_heat, cost_elz = rt.cost_elz, cost_water = rt.cost_water;
+        rew = rt.rew;
         R.b.cum += rew;
         if (changed) { rew -= setc.y; if (P.track_changes) { need_c(P, e, R); R.c.nchg += 1; R.c_dirty = true; } }
         *rew_out = (OUT)rew;
@@ -765,15 +779,24 @@ enum { LAD_T1_START_P_F = 0, LAD_T2_START_F_P, LAD_T_P_F, LAD_T_F_P, LAD_T1_P_F_
        LAD_T4_P_F_P, LAD_T45_P_F_P, LAD_T5_P_F_P, LAD_T1_F_P_F, LAD_T2_F_P_F, LAD_T23_F_P_F, LAD_T3_F_P_F, LAD_T34_F_P_F,
        LAD_T4_F_P_F, LAD_T45_F_P_F, LAD_T5_F_P_F, LAD_I_FULL, LAD_J_FULL, LAD_N };
 
+struct RewC {                    // reward (:280-334) and normalisation (:206-217) constants, named as in DevParams (reward_ref reads either)
+    double c_mol, Hu_ch4, Hu_h2, dt_cp_evap, heat_price, o2_price, eeg, eta_chp, one_m_eta_chp, M_co2, M_h2o,
+           rho, water_price, min_load, max_h2, c_m2, c_m3, sim_step_d;
+    double T_lo, T_rng, h2_lo, h2_rng, ch4_lo, ch4_rng, h2r_lo, h2r_rng, h2o_lo, h2o_rng, heat_lo, heat_rng;
+};
+
 struct HotParams {
     int N, S, sim_step, eps_sim_steps, F, nT, tape_len, track_changes, flat;
     int key_cold_max, key_hot_min, key_standby_max, n_hours, n_days, hstride, dstride;
     unsigned off_featB, off_gasn, off_euan, off_sc;   // element offsets into pool32 (featA at 0; sin/cos pairs at off_sc)
     unsigned off_gas, off_eua;                        // element offsets into pool64 (el at 0)
+    unsigned o64_featA, o64_featB, o64_gasn, o64_euan, o64_sc;   // float64 outputs: the same feature series as doubles, in pool64
     unsigned long long noise_seed;
     long long env_offset;
     double noise_sigma, k_chp, k_eua;
     const RecFast* recf;
+    const Rec* rec;                                   // float64 outputs: raw window means, reward in the reference's operand order
+    RewC rc;
     const double* tape;
     const float* pool32;
     const double* pool64;
@@ -797,14 +820,62 @@ struct HotRegs {                 // per-env state in registers
     int act_d, nctr;
 };
 
+// float32 outputs: strength-reduced records (RecFast) and float32 feature series; float64 outputs: the raw window records (Rec),
+// float64 series, reward and normalisation evaluated as the reference writes them (reward_ref)
+template <typename OUT> struct HotTypes;
+template <> struct HotTypes<float> { typedef RecFast rec_t; typedef float2 sc_t; };
+template <> struct HotTypes<double> { typedef Rec rec_t; typedef double2 sc_t; };
+
+template <typename OUT>
 struct HotLoads {                // everything front() fetched for one step
-    float fa[13], fb[13];        // Pot_Reward, Part_Full ('raw': Elec_Price; Gas_Price[2], EUA_Price[2] in fb[0..3])
-    float2 sc;                   // Temp_hour_enc_sin / cos
-    unsigned hb4, db4, kk8;      // byte offsets of the step's hour / day / step-count entries in the pools
+    OUT fa[13], fb[13];          // Pot_Reward, Part_Full ('raw': Elec_Price; Gas_Price[2], EUA_Price[2] in fb[0..3])
+    typename HotTypes<OUT>::sc_t sc;   // Temp_hour_enc_sin / cos
+    unsigned hb4, db4, kk8;      // byte offsets (of 4-byte elements) of the step's hour / day / step-count entries in the pools
     double el, gas, eua;
-    RecFast rec;
+    typename HotTypes<OUT>::rec_t rec;
     bool changed;
 };
+
+__device__ __forceinline__ const RecFast* rec_table(const HotParams& P, const RecFast*) { return P.recf; }
+__device__ __forceinline__ const Rec* rec_table(const HotParams& P, const Rec*) { return P.rec; }
+// reward of the step (before the state-change penalty): price-linear form / reference form
+__device__ __forceinline__ double hot_reward(const HotParams& P, const RecFast& r, double el, double gas, double eua, double b_s3)
+{
+    return r.base + r.ch4 * (b_s3 * P.k_chp + P.k_eua * eua) + r.c_gas * gas - r.c_el * el;
+}
+__device__ __forceinline__ double hot_reward(const HotParams& P, const Rec& r, double el, double gas, double eua, double b_s3)
+{
+    return reward_ref(P.rc, r.m[0], r.m[1], r.m[2], r.m[3], r.m[4], el, gas, eua, b_s3).rew;
+}
+// normalised T_cat, H2, CH4, H2_res, H2O, el_heating (:212-217): pre-computed float32 / evaluated in float64
+template <int Q> __device__ __forceinline__ float rec_feat(const HotParams&, const RecFast& r) { return r.feat[Q]; }
+template <int Q> __device__ __forceinline__ double rec_feat(const HotParams& P, const Rec& r)
+{
+    const RewC& c = P.rc;
+    return Q == 0 ? (r.T - c.T_lo) / c.T_rng : Q == 1 ? (r.m[0] - c.h2_lo) / c.h2_rng : Q == 2 ? (r.m[1] - c.ch4_lo) / c.ch4_rng
+         : Q == 3 ? (r.m[2] - c.h2r_lo) / c.h2r_rng : Q == 4 ? (r.m[3] - c.h2o_lo) / c.h2o_rng : (r.m[4] - c.heat_lo) / c.heat_rng;
+}
+// the six record features into an observation sink, columns o + 1 .. o + 6
+template <bool U, class Sink, class RecT>
+__device__ __forceinline__ void put_rec_feats(const HotParams& P, const Sink& row, int o, const RecT& r)
+{
+    if (U) {
+        row.put_u(o + 1, rec_feat<0>(P, r)); row.put_u(o + 2, rec_feat<1>(P, r)); row.put_u(o + 3, rec_feat<2>(P, r));
+        row.put_u(o + 4, rec_feat<3>(P, r)); row.put_u(o + 5, rec_feat<4>(P, r)); row.put_u(o + 6, rec_feat<5>(P, r));
+    } else {
+        row.put(o + 1, rec_feat<0>(P, r)); row.put(o + 2, rec_feat<1>(P, r)); row.put(o + 3, rec_feat<2>(P, r));
+        row.put(o + 4, rec_feat<3>(P, r)); row.put(o + 5, rec_feat<4>(P, r)); row.put(o + 6, rec_feat<5>(P, r));
+    }
+}
+// feature series of the element type: float32 pool / the float64 copies behind the prices in pool64
+__device__ __forceinline__ const float* series(const HotParams& P, const float*, int which)
+{
+    return P.pool32 + (which == 0 ? 0u : which == 1 ? P.off_featB : which == 2 ? P.off_gasn : which == 3 ? P.off_euan : P.off_sc);
+}
+__device__ __forceinline__ const double* series(const HotParams& P, const double*, int which)
+{
+    return P.pool64 + (which == 0 ? P.o64_featA : which == 1 ? P.o64_featB : which == 2 ? P.o64_gasn : which == 3 ? P.o64_euan : P.o64_sc);
+}
 
 enum { NOISE_NONE = 0, NOISE_TAPE = 1, NOISE_RNG = 2 };
 
@@ -903,30 +974,31 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
 
 // front half of a step: clock (:442-447), market loads, state machine, record gather -- every load of the step in one burst
 // market + clock features of one step: 13 + 13 (or 13 + 4) + 2 float32 loads, merged by the backend into dwordx4
-template <bool MOD>
-__device__ __forceinline__ void hot_load_market(const HotParams& P, HotLoads& Q)
+template <bool MOD, typename OUT>
+__device__ __forceinline__ void hot_load_market(const HotParams& P, HotLoads<OUT>& Q)
 {
-    const float* pA = P.pool32;
+    constexpr unsigned W = sizeof(OUT) / 4;                 // byte offsets are kept for 4-byte elements
+    const OUT* pA = series(P, (const OUT*)nullptr, 0);
 #pragma unroll
-    for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<float>(pA + q, Q.hb4);     // uniform (base + q) + one lane offset
+    for (int q = 0; q < 13; q++) Q.fa[q] = ld_off<OUT>(pA + q, Q.hb4 * W);   // uniform (base + q) + one lane offset
     if (MOD) {
-        const float* pB = P.pool32 + P.off_featB;
+        const OUT* pB = series(P, (const OUT*)nullptr, 1);
 #pragma unroll
-        for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<float>(pB + q, Q.hb4);
+        for (int q = 0; q < 13; q++) Q.fb[q] = ld_off<OUT>(pB + q, Q.hb4 * W);
     } else {
-        const float* pG = P.pool32 + P.off_gasn;
-        const float* pU = P.pool32 + P.off_euan;
-        Q.fb[0] = ld_off<float>(pG, Q.db4); Q.fb[1] = ld_off<float>(pG + 1, Q.db4);
-        Q.fb[2] = ld_off<float>(pU, Q.db4); Q.fb[3] = ld_off<float>(pU + 1, Q.db4);
+        const OUT* pG = series(P, (const OUT*)nullptr, 2);
+        const OUT* pU = series(P, (const OUT*)nullptr, 3);
+        Q.fb[0] = ld_off<OUT>(pG, Q.db4 * W); Q.fb[1] = ld_off<OUT>(pG + 1, Q.db4 * W);
+        Q.fb[2] = ld_off<OUT>(pU, Q.db4 * W); Q.fb[3] = ld_off<OUT>(pU + 1, Q.db4 * W);
     }
-    Q.sc = ld_off<float2>(P.pool32 + P.off_sc, Q.kk8);
+    Q.sc = ld_off<typename HotTypes<OUT>::sc_t>(series(P, (const OUT*)nullptr, 4), Q.kk8 * W);
 }
 
 // k1 = step count after this step: UNIFORM (the hot kernels only run on a synchronised batch), so the clock arithmetic of
 // :442-445 is scalar; only the episode offset act_ep_d differs between envs
-template <bool MOD, int NOISE>
+template <bool MOD, int NOISE, typename OUT>
 __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
-                                          HotRegs& R, int act, int e, int k1, HotLoads& Q)
+                                          HotRegs& R, int act, int e, int k1, HotLoads<OUT>& Q)
 {
     const unsigned mset = (R.flags >> 15) & 3;
     const int secs = k1 * P.sim_step;
@@ -938,33 +1010,36 @@ __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, c
     }
     const unsigned hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u, db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
     Q.hb4 = hb4; Q.db4 = db4; Q.kk8 = (unsigned)min(k1, P.eps_sim_steps) * 8u;
-    hot_load_market<MOD>(P, Q);
+    hot_load_market<MOD, OUT>(P, Q);
     Q.el = ld_off<double>(P.pool64, hb4 * 2u);
     Q.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
     Q.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
     const int ridx = hot_ints<NOISE>(P, L, lut16, lds_lut, R, act, e, Q.changed);
-    Q.rec = ld_off<RecFast>(P.recf, (unsigned)ridx * 64u);
+    typedef typename HotTypes<OUT>::rec_t rec_t;
+    Q.rec = ld_off<rec_t>(rec_table(P, (const rec_t*)nullptr), (unsigned)ridx * 64u);
 }
 
 // back half: reward (:280-334 in its price-linear form) and bookkeeping
-__device__ __forceinline__ float hot_back(const HotParams& P, HotRegs& R, const HotLoads& Q, const double2 setc, int e, bool live)
+template <typename OUT>
+__device__ __forceinline__ OUT hot_back(const HotParams& P, HotRegs& R, const HotLoads<OUT>& Q, const double2 setc, int e, bool live)
 {
     R.flags = (R.flags & 0x1FFFFu) | ((unsigned)Q.rec.tkey << 17);           // Meth_T_cat = op[-1, 1] (:452)
-    double rew = Q.rec.base + Q.rec.ch4 * (setc.x * P.k_chp + P.k_eua * Q.eua) + Q.rec.c_gas * Q.gas - Q.rec.c_el * Q.el;
+    double rew = hot_reward(P, Q.rec, Q.el, Q.gas, Q.eua, setc.x);
     R.cum += rew;
     rew -= Q.changed ? setc.y : 0.0;                                         // :332 (setc.y = r_0 * penalty, 0 by default)
     if (P.track_changes) { if (Q.changed && live) P.st_c[e].nchg += 1; }     // lanes past N shadow env N-1: no side effects
-    return (float)rew;
+    return (OUT)rew;
 }
 
-template <bool FM, bool MOD = true>
+template <bool FM, bool MOD = true, typename OUT = float>
 struct HotRow {                  // observation row addressing: uniform base + 32-bit lane byte offset (feature q adds q * qbytes)
+    static constexpr unsigned B = sizeof(OUT);
     char* base; unsigned boff; unsigned qbytes; bool flat;
-    __device__ __forceinline__ HotRow(float* b, const HotParams& P, int e)
-        : base((char*)b), boff(FM ? (unsigned)e * 4u : (unsigned)e * (unsigned)P.F * 4u), qbytes(FM ? (unsigned)P.N * 4u : 4u), flat(!FM && P.flat) {}
-    __device__ __forceinline__ void put(int q, float v) const;
+    __device__ __forceinline__ HotRow(OUT* b, const HotParams& P, int e)
+        : base((char*)b), boff(FM ? (unsigned)e * B : (unsigned)e * (unsigned)P.F * B), qbytes(FM ? (unsigned)P.N * B : B), flat(!FM && P.flat) {}
+    __device__ __forceinline__ void put(int q, OUT v) const;
     // same address as (uniform pointer advanced by SALU) + (the one lane offset): no per-feature offset registers
-    __device__ __forceinline__ void put_u(int q, float v) const;
+    __device__ __forceinline__ void put_u(int q, OUT v) const;
 };
 
 // SB3_FLAT layout (price_ahead = 13): canonical column q -> column of the flat row, sub-spaces in sorted key order
@@ -982,56 +1057,58 @@ __host__ __device__ constexpr int flat_col(int q)
          : q == 17 ? 22 : q == 18 ? 28 : q == 19 ? 20 : q == 20 ? 0 : q == 21 ? 21 : q == 22 ? 19 : q == 23 ? 3 : q == 24 ? 30 : 29;
 }
 
-template <bool FM, bool MOD>
-__device__ __forceinline__ void HotRow<FM, MOD>::put(int q, float v) const
+template <bool FM, bool MOD, typename OUT>
+__device__ __forceinline__ void HotRow<FM, MOD, OUT>::put(int q, OUT v) const
 {
     constexpr int QS = MOD ? 26 : 17;
     if (!FM && flat) {
         if (q == QS) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) st_off<float>(base, boff + (unsigned)(flat_col<MOD>(QS) + j) * 4u, ((int)v == j) ? 1.f : 0.f);
-        } else st_off<float>(base, boff + (unsigned)flat_col<MOD>(q) * 4u, v);
-    } else st_off<float>(base, boff + (unsigned)q * qbytes, v);
+            for (int j = 0; j < 6; j++) st_off<OUT>(base, boff + (unsigned)(flat_col<MOD>(QS) + j) * B, ((int)v == j) ? (OUT)1 : (OUT)0);
+        } else st_off<OUT>(base, boff + (unsigned)flat_col<MOD>(q) * B, v);
+    } else st_off<OUT>(base, boff + (unsigned)q * qbytes, v);
 }
-template <bool FM, bool MOD>
-__device__ __forceinline__ void HotRow<FM, MOD>::put_u(int q, float v) const
+template <bool FM, bool MOD, typename OUT>
+__device__ __forceinline__ void HotRow<FM, MOD, OUT>::put_u(int q, OUT v) const
 {
     if (!FM && flat) put(q, v);
-    else st_off<float>(base + (size_t)q * qbytes, boff, v);
+    else st_off<OUT>(base + (size_t)q * qbytes, boff, v);
 }
 
 // Row-major observations ([N][F], the reference's layout): a lane's row is 140 B away from its neighbour's, so per-feature
 // stores would be 64 scattered 4-byte writes each.  Instead every wave transposes its 64 rows through a private LDS tile and
 // writes them back as ONE contiguous block of 64 * F floats with dwordx4 stores (64 * 140 B = 70 full 128-byte lines).
 typedef float vf4 __attribute__((ext_vector_type(4)));
-template <bool MOD, bool FLAT>
+template <bool MOD, bool FLAT, typename OUT = float>
 struct RowTile {
     static constexpr int FC = MOD ? 35 : 26;               // canonical row width
     static constexpr int FMAX = FC + 5;                    // SB3_FLAT: METH_STATUS one-hot (6 columns for 1)
     static constexpr int F = FLAT ? FMAX : FC;
     static constexpr int QS = MOD ? 26 : 17;               // canonical column of METH_STATUS
-    static constexpr int N4 = 16 * F;                      // float4 per wave block (560 / 416; flat: 640 / 496)
+    static constexpr int EPP = 16 / (int)sizeof(OUT);      // elements per 16-byte piece (4 floats / 2 doubles)
+    static constexpr int N4 = 64 * F / EPP;                // 16-byte pieces per wave block (float: 560 / 416, flat 640 / 496; double: 1120 / 832)
     // LDS row pitch: F = 40 would put lanes l and l + 4 on the same bank for every column (16-way conflicts on each of the 40
     // writes: measured 2.15 us per step); 41 is conflict-free, and because 40 is a multiple of 4 a float4 of the output
     // image never straddles two tile rows
+    // (float64 rows: pitch 35 doubles = 70 dwords -- lanes l, l + 1 start 6 banks apart, an 8-byte store per lane is conflict-free)
     static constexpr int PITCH = (F == 40) ? 41 : F;
-    static constexpr int TILE = 64 * PITCH;                // floats per wave
-    float* t;                                              // this wave's [64][PITCH] tile
+    static constexpr int TILE = 64 * PITCH;                // elements per wave
+    OUT* t;                                                // this wave's [64][PITCH] tile
     int lane;
-    __device__ __forceinline__ RowTile(float* tiles, int wave) : t(tiles + wave * TILE), lane(threadIdx.x & 63) {}
-    __device__ __forceinline__ void put(int q, float v) const
+    __device__ __forceinline__ RowTile(OUT* tiles, int wave) : t(tiles + wave * TILE), lane(threadIdx.x & 63) {}
+    __device__ __forceinline__ void put(int q, OUT v) const
     {
-        float* r = t + lane * PITCH;
+        OUT* r = t + lane * PITCH;
         if (FLAT) {
             if (q == QS) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) r[flat_col<MOD>(QS) + j] = ((int)v == j) ? 1.f : 0.f;
+                for (int j = 0; j < 6; j++) r[flat_col<MOD>(QS) + j] = ((int)v == j) ? (OUT)1 : (OUT)0;
             } else r[flat_col<MOD>(q)] = v;
         } else r[q] = v;
     }
-    __device__ __forceinline__ void put_u(int q, float v) const { put(q, v); }
+    __device__ __forceinline__ void put_u(int q, OUT v) const { put(q, v); }
     // rows = address of the wave's first row; all 64 lanes of the wave must be live
-    __device__ __forceinline__ void flush(float* rows) const
+    __device__ __forceinline__ void flush(OUT* rows) const
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1041,8 +1118,8 @@ struct RowTile {
             if (g < N4) {
                 vf4 v;
                 if (PITCH == F) v = ((const vf4*)t)[g];
-                else {
-                    const float* src = t + (g / (F / 4)) * PITCH + (g % (F / 4)) * 4;      // 4-byte aligned only
+                else {                                     // padded pitch: float32 flat rows only
+                    const float* src = (const float*)t + (g / (F / 4)) * PITCH + (g % (F / 4)) * 4;      // 4-byte aligned only
                     v = vf4{src[0], src[1], src[2], src[3]};
                 }
                 __builtin_nontemporal_store(v, (vf4*)rows + g);
@@ -1052,17 +1129,16 @@ struct RowTile {
     }
 };
 
-template <bool MOD, class Sink>
-__device__ __forceinline__ void hot_store_obs(const Sink& row, const HotLoads& Q, int s)
+template <bool MOD, class Sink, typename OUT>
+__device__ __forceinline__ void hot_store_obs(const HotParams& P, const Sink& row, const HotLoads<OUT>& Q, int s)
 {
 #pragma unroll
     for (int q = 0; q < 13; q++) row.put(q, Q.fa[q]);
 #pragma unroll
     for (int q = 0; q < (MOD ? 13 : 4); q++) row.put(13 + q, Q.fb[q]);
     constexpr int o = MOD ? 26 : 17;
-    row.put(o + 0, (float)s);
-#pragma unroll
-    for (int q = 0; q < 6; q++) row.put(o + 1 + q, Q.rec.feat[q]);
+    row.put(o + 0, (OUT)s);
+    put_rec_feats<false>(P, row, o, Q.rec);
     row.put(o + 7, Q.sc.x);
     row.put(o + 8, Q.sc.y);
 }
@@ -1094,14 +1170,14 @@ __device__ __forceinline__ void hot_fetch(int actk, const void* actions, size_t 
 
 // one vector step, no env terminates (host-guaranteed); lanes past N shadow env N-1 and store nothing
 // LAY: 0 row-major, 1 feature-major, 2 SB3_FLAT rows (the PTG_OBS_* values)
-template <int LAY, bool MOD, int NOISE>
+template <int LAY, bool MOD, int NOISE, typename OUT>
 __global__ void __launch_bounds__(256)
-k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0, float* __restrict__ obs, float* __restrict__ rew,
+k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0, OUT* __restrict__ obs, OUT* __restrict__ rew,
            uint8_t* __restrict__ done)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
     __shared__ HotLds L;
-    __shared__ __attribute__((aligned(16))) float s_tile[FM ? 4 : 4 * RowTile<MOD, FLAT>::TILE];   // row-major / flat: one tile per wave
+    __shared__ __attribute__((aligned(16))) OUT s_tile[FM ? 4 : 4 * RowTile<MOD, FLAT, OUT>::TILE];   // row-major / flat: one tile per wave
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
@@ -1114,19 +1190,19 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const int act = hot_decode(actk, P, ri, rf, R.flags);
-    HotLoads Q;
-    hot_front<MOD, NOISE>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
-    const float r = hot_back(P, R, Q, setc, e, live);
+    HotLoads<OUT> Q;
+    hot_front<MOD, NOISE, OUT>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
+    const OUT r = hot_back<OUT>(P, R, Q, setc, e, live);
     const bool wave_full = __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // e_raw of lane 0: the wave's first env
     if (!FM && wave_full) {
-        float* rows = obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
-        const RowTile<MOD, FLAT> tile(s_tile, threadIdx.x >> 6);
-        hot_store_obs<MOD>(tile, Q, R.flags & 7);
+        OUT* rows = obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
+        const RowTile<MOD, FLAT, OUT> tile(s_tile, threadIdx.x >> 6);
+        hot_store_obs<MOD>(P, tile, Q, R.flags & 7);
         tile.flush(rows);
     }
     if (live) {
-        if (FM || !wave_full) hot_store_obs<MOD>(HotRow<FM, MOD>(obs, P, e), Q, R.flags & 7);
-        st_off<float>(rew, (unsigned)e * 4u, r);
+        if (FM || !wave_full) hot_store_obs<MOD>(P, HotRow<FM, MOD, OUT>(obs, P, e), Q, R.flags & 7);
+        st_off<OUT>(rew, (unsigned)e * (unsigned)sizeof(OUT), r);
         st_off<uint8_t>(done, (unsigned)e, 0);
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
         StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
@@ -1144,26 +1220,28 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
 // iteration earlier), so no wave ever waits on a load it has just issued.  One LDS-only barrier per step.
 struct PcSlot { unsigned w[256]; };      // record index | METH_STATUS << 24 | changed << 27
 
+template <typename OUT>
 struct PcMarket {
-    float fa[13], fb[13];
+    OUT fa[13], fb[13];
     double el, gas, eua;
 };
 
-template <bool MOD>
-__device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4, unsigned db4, PcMarket& M)
+template <bool MOD, typename OUT>
+__device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4, unsigned db4, PcMarket<OUT>& M)
 {
-    const float* pA = P.pool32;
+    constexpr unsigned W = sizeof(OUT) / 4;
+    const OUT* pA = series(P, (const OUT*)nullptr, 0);
 #pragma unroll
-    for (int q = 0; q < 13; q++) M.fa[q] = ld_off<float>(pA + q, hb4);
+    for (int q = 0; q < 13; q++) M.fa[q] = ld_off<OUT>(pA + q, hb4 * W);
     if (MOD) {
-        const float* pB = P.pool32 + P.off_featB;
+        const OUT* pB = series(P, (const OUT*)nullptr, 1);
 #pragma unroll
-        for (int q = 0; q < 13; q++) M.fb[q] = ld_off<float>(pB + q, hb4);
+        for (int q = 0; q < 13; q++) M.fb[q] = ld_off<OUT>(pB + q, hb4 * W);
     } else {
-        const float* pG = P.pool32 + P.off_gasn;
-        const float* pU = P.pool32 + P.off_euan;
-        M.fb[0] = ld_off<float>(pG, db4); M.fb[1] = ld_off<float>(pG + 1, db4);
-        M.fb[2] = ld_off<float>(pU, db4); M.fb[3] = ld_off<float>(pU + 1, db4);
+        const OUT* pG = series(P, (const OUT*)nullptr, 2);
+        const OUT* pU = series(P, (const OUT*)nullptr, 3);
+        M.fb[0] = ld_off<OUT>(pG, db4 * W); M.fb[1] = ld_off<OUT>(pG + 1, db4 * W);
+        M.fb[2] = ld_off<OUT>(pU, db4 * W); M.fb[3] = ld_off<OUT>(pU + 1, db4 * W);
     }
     M.el = ld_off<double>(P.pool64, hb4 * 2u);
     M.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
@@ -1206,9 +1284,36 @@ k_refresh(const void* __restrict__ recf, const unsigned short* __restrict__ rkey
     asm volatile("" :: "v"(sink));
 }
 
-template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL>
+// What the NEXT hour adds to a consumer's market registers: the 13-hour windows slide by one (window(H + 1)[q] = window(H)[q + 1]),
+// so one new element per series and the three prices are all that has to be fetched ahead of the hour change -- not a second
+// copy of the 26 features (58 registers of float64 features that made the float64 kernel spill).
+template <bool MOD, typename OUT>
+struct PcNext {
+    OUT fa12, fb12;              // Pot_Reward / Part_Full ('raw': Elec_Price) of hour H + 13
+    OUT fbr[MOD ? 1 : 4];        // 'raw': Gas_Price[2], EUA_Price[2] of the next hour's day
+    double el, gas, eua;
+};
+
+template <bool MOD, typename OUT>
+__device__ __forceinline__ void pc_load_next(const HotParams& P, unsigned hb4, unsigned db4, PcNext<MOD, OUT>& X)
+{
+    constexpr unsigned W = sizeof(OUT) / 4;
+    X.fa12 = ld_off<OUT>(series(P, (const OUT*)nullptr, 0) + 12, hb4 * W);
+    if (MOD) X.fb12 = ld_off<OUT>(series(P, (const OUT*)nullptr, 1) + 12, hb4 * W);
+    else {
+        const OUT* pG = series(P, (const OUT*)nullptr, 2);
+        const OUT* pU = series(P, (const OUT*)nullptr, 3);
+        X.fbr[0] = ld_off<OUT>(pG, db4 * W); X.fbr[1] = ld_off<OUT>(pG + 1, db4 * W);
+        X.fbr[2] = ld_off<OUT>(pU, db4 * W); X.fbr[3] = ld_off<OUT>(pU + 1, db4 * W);
+    }
+    X.el = ld_off<double>(P.pool64, hb4 * 2u);
+    X.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
+    X.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
+}
+
+template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT>
 __global__ void __launch_bounds__(512)
-k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, float* __restrict__ obs, float* __restrict__ rew,
+k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
@@ -1217,8 +1322,15 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     const int nwork = blockDim.x;
     HotLds& L = *(HotLds*)s_dyn;
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
-    float* s_tiles = (float*)((unsigned char*)slot + 2 * sizeof(PcSlot));               // row-major: one [64][F] tile per consumer wave
-    unsigned char* s_act = (unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * RowTile<MOD, FLAT>::TILE * 4);   // [T][NP] decoded actions
+    typedef typename HotTypes<OUT>::rec_t rec_t;
+    constexpr unsigned B = sizeof(OUT);
+    OUT* s_tiles = (OUT*)((unsigned char*)slot + 2 * sizeof(PcSlot));                   // row-major: one [64][F] tile per consumer wave
+    // float64 outputs: the 26 (17) per-env market features of the current hour live in LDS, [feature][env] -- as registers they
+    // are 52 of the 256 a lane may have, and the kernel spilled.  The two 13-hour windows are rings: slot of element q = (q + head) mod 13
+    constexpr bool MLDS = sizeof(OUT) == 8;
+    constexpr int NFM = MOD ? 26 : 17;
+    OUT* s_mkt = (OUT*)((unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * RowTile<MOD, FLAT, OUT>::TILE * B));
+    unsigned char* s_act = (unsigned char*)s_mkt + (MLDS ? (size_t)NFM * NP * B : 0);      // [T][NP] decoded actions
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
     const int lx = producer ? threadIdx.x : threadIdx.x - NP;
@@ -1337,19 +1449,37 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u;
         db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
     };
-    PcMarket M, Mn;                                         // consumer: market data of the step being finished / of the next hour
+    PcMarket<OUT> M;                                        // consumer: market data of the step being finished ...
+    PcNext<MOD, OUT> Mn;                                    // ... and what the next hour adds to it
     double2 setc = make_double2(0.0, 0.0);
-    int hour_cur = 0;
+    int hour_cur = 0, head = 0;                             // head: first slot of the feature rings (uniform: the hour is)
+    auto mkt_to_lds = [&]() {                               // the window just loaded into M -> LDS, rings at head 0
+        if (MLDS) {
+#pragma unroll
+            for (int q = 0; q < 13; q++) s_mkt[q * NP + lx] = M.fa[q];
+#pragma unroll
+            for (int q = 0; q < (MOD ? 13 : 4); q++) s_mkt[(13 + q) * NP + lx] = M.fb[q];
+            head = 0;
+        }
+    };
+    auto mk = [&](const int q) -> OUT {                     // canonical market column q of the current hour
+        if (!MLDS) return q < 13 ? M.fa[q] : M.fb[q - 13];
+        if (q >= 13 && !MOD) return s_mkt[q * NP + lx];
+        int r = (q < 13 ? q : q - 13) + head;
+        r = r >= 13 ? r - 13 : r;
+        return s_mkt[((q < 13 ? 0 : 13) + r) * NP + lx];
+    };
     unsigned tk = 0;                                        // producer: key of the window entered by the previous step (in flight)
-    RecFast recA, recB; unsigned wA = 0, wB = 0;            // consumer: records in flight (ping-pong: no copies of pending loads)
+    rec_t recA, recB; unsigned wA = 0, wB = 0;              // consumer: records in flight (ping-pong: no copies of pending loads)
     if (!producer) {
         setc = P.setc[mset];
         unsigned hb4, db4;
         offsets(k0 + 1, hb4, db4);
         hour_cur = ((k0 + 1) * P.sim_step) / 3600;
-        pc_load_market<MOD>(P, hb4, db4, M);
+        pc_load_market<MOD, OUT>(P, hb4, db4, M);
+        mkt_to_lds();
     }
-    const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * 4u;
+    const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * B;
     char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of the step being finished
     // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
     // stores and the gathers just issued -- once per step, which serialises exactly what this kernel overlaps
@@ -1363,54 +1493,77 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         tk = ld_off<unsigned short>(rkey, (unsigned)ridx * 2u);
         slot[it & 1].w[lx] = (unsigned)ridx | ((R.flags & 7u) << 24) | (changed ? (1u << 27) : 0u);
     };
-    auto request = [&](const int t, RecFast& rec, unsigned& w) {                  // consumer: record gather of step t
+    auto request = [&](const int t, rec_t& rec, unsigned& w) {                    // consumer: record gather of step t
         w = slot[t & 1].w[lx];
-        rec = ld_off<RecFast>(P.recf, (w & 0xFFFFFFu) * 64u);
+        rec = ld_off<rec_t>(rec_table(P, (const rec_t*)nullptr), (w & 0xFFFFFFu) * 64u);
     };
     // consumer: finish step t (record already requested), optionally requesting step t+1 in between.  Issue order = retire
     // order (vmcnt): clock + next-hour loads, then the gather, then the stores -- nothing the stores need sits behind the gather
-    auto finish = [&](const int t, const RecFast& rec, const unsigned w, const bool more, RecFast& recN, unsigned& wN) {
+    auto finish = [&](const int t, const rec_t& rec, const unsigned w, const bool more, rec_t& recN, unsigned& wN) {
         const int k1 = k0 + t + 1;
         const int hour_next = ((k1 + 1) * P.sim_step) / 3600;
         const bool reload = (hour_next != hour_cur) && (t + 1 < T);
-        const float2 sc = ld_off<float2>(P.pool32 + P.off_sc, (unsigned)min(k1, P.eps_sim_steps) * 8u);
+        const auto sc = ld_off<typename HotTypes<OUT>::sc_t>(series(P, (const OUT*)nullptr, 4), (unsigned)min(k1, P.eps_sim_steps) * 2u * B);
+        const bool slide = hour_next == hour_cur + 1;       // uniform (always, for steps of at most an hour)
+        unsigned hb4n = 0, db4n = 0;
         if (reload) {                                       // uniform branch
-            unsigned hb4, db4;
-            offsets(k1 + 1, hb4, db4);
-            pc_load_market<MOD>(P, hb4, db4, Mn);
+            offsets(k1 + 1, hb4n, db4n);
+            if (slide) pc_load_next<MOD, OUT>(P, hb4n, db4n, Mn);
         }
         if (more) request(t + 1, recN, wN);
         const bool changed = (w >> 27) & 1u;
-        double rw = rec.base + rec.ch4 * (setc.x * P.k_chp + P.k_eua * M.eua) + rec.c_gas * M.gas - rec.c_el * M.el;
+        double rw = hot_reward(P, rec, M.el, M.gas, M.eua, setc.x);
         R.cum += rw;
         rw -= changed ? setc.y : 0.0;                                            // :332
         if (P.track_changes) { if (changed && live) P.st_c[e].nchg += 1; }
         auto emit = [&](const auto& row) {
 #pragma unroll
-            for (int q = 0; q < 13; q++) row.put_u(q, M.fa[q]);
-#pragma unroll
-            for (int q = 0; q < (MOD ? 13 : 4); q++) row.put_u(13 + q, M.fb[q]);
+            for (int q = 0; q < (MOD ? 26 : 17); q++) row.put_u(q, mk(q));
             constexpr int o = MOD ? 26 : 17;
-            row.put_u(o + 0, (float)((w >> 24) & 7u));
-#pragma unroll
-            for (int q = 0; q < 6; q++) row.put_u(o + 1 + q, rec.feat[q]);
+            row.put_u(o + 0, (OUT)((w >> 24) & 7u));
+            put_rec_feats<true>(P, row, o, rec);
             row.put_u(o + 7, sc.x);
             row.put_u(o + 8, sc.y);
         };
         if (!FM && wave_full) {                             // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
-            float* rows = (float*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
+            OUT* rows = (OUT*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
             const int cw = (int)(threadIdx.x >> 6) - (NP >> 6);
-            const RowTile<MOD, FLAT> tile(s_tiles, cw);
+            const RowTile<MOD, FLAT, OUT> tile(s_tiles, cw);
             emit(tile);
             tile.flush(rows);
         }
         if (live) {
-            if (FM || !wave_full) emit(HotRow<FM, MOD>((float*)obs_t, P, e));
-            st_off<float>(rew_t, (unsigned)e * 4u, (float)rw);
+            if (FM || !wave_full) emit(HotRow<FM, MOD, OUT>((OUT*)obs_t, P, e));
+            st_off<OUT>(rew_t, (unsigned)e * B, (OUT)rw);
             st_off<uint8_t>(done_t, (unsigned)e, 0);
         }
-        obs_t += NF4; rew_t += (size_t)P.N * 4u; done_t += P.N;
-        if (reload) { M = Mn; hour_cur = hour_next; }
+        obs_t += NF4; rew_t += (size_t)P.N * B; done_t += P.N;
+        if (reload) {
+            if (slide && MLDS) {                            // the new elements take the slots of the ones that left the windows
+                s_mkt[head * NP + lx] = Mn.fa12;
+                if (MOD) s_mkt[(13 + head) * NP + lx] = Mn.fb12;
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) s_mkt[(13 + q) * NP + lx] = Mn.fbr[q];
+                }
+                head = head + 1 == 13 ? 0 : head + 1;
+                M.el = Mn.el; M.gas = Mn.gas; M.eua = Mn.eua;
+            } else if (slide) {
+#pragma unroll
+                for (int q = 0; q < 12; q++) M.fa[q] = M.fa[q + 1];
+                M.fa[12] = Mn.fa12;
+                if (MOD) {
+#pragma unroll
+                    for (int q = 0; q < 12; q++) M.fb[q] = M.fb[q + 1];
+                    M.fb[12] = Mn.fb12;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) M.fb[q] = Mn.fbr[q];
+                }
+                M.el = Mn.el; M.gas = Mn.gas; M.eua = Mn.eua;
+            } else { pc_load_market<MOD, OUT>(P, hb4n, db4n, M); mkt_to_lds(); }      // steps longer than an hour: a plain (waited-for) reload
+            hour_cur = hour_next;
+        }
     };
     // iteration `it`: producers run step it (while it < T); consumers request step it-1 and finish step it-2.  The two roles
     // run SEPARATE loops with the same number (T + 1) of barriers: the role is wave-uniform, and with one role per loop the
@@ -1615,7 +1768,9 @@ struct ptg_env {
     unsigned short* d_rkey = nullptr;   // temperature keys of all window records (k_rollout_pc producers)
     float* d_pool32 = nullptr; double* d_pool64 = nullptr;
     unsigned off_featB = 0, off_gasn = 0, off_euan = 0, off_gas = 0, off_eua = 0, off_sc = 0;
+    unsigned o64_featA = 0, o64_featB = 0, o64_gasn = 0, o64_euan = 0, o64_sc = 0;
     std::vector<float> pool32_host;
+    std::vector<double> pool64_host;
     int* d_ladder = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
     // VecNormalize reward normalisation (ptg_vn_*): per-env discounted returns, running (mean, var, count), scratch
@@ -1849,13 +2004,16 @@ int build_market(ptg_env* h, const ptg_market* sets, int n_sets)
         h->off_gasn = (unsigned)pool.size(); pool.insert(pool.end(), gasn.begin(), gasn.end());
         h->off_euan = (unsigned)pool.size(); pool.insert(pool.end(), euan.begin(), euan.end());
         h->pool32_host = pool;                            // uploaded by ptg_create once the sin/cos table is appended
-        std::vector<double> p64;
+        // pool64 = [el | gas | eua | featA | featB | gas_n | eua_n | sin,cos pairs]: prices for every hot kernel, the float64 feature
+        // series for the float64-output ones (uploaded by ptg_create once the sin/cos table is appended)
+        std::vector<double>& p64 = h->pool64_host;
         p64.insert(p64.end(), el.begin(), el.end());
         h->off_gas = (unsigned)p64.size(); p64.insert(p64.end(), gas.begin(), gas.end());
         h->off_eua = (unsigned)p64.size(); p64.insert(p64.end(), eua.begin(), eua.end());
-        double* d_p64;
-        if ((rc = dev_upload(h, &d_p64, p64.data(), p64.size()))) return rc;
-        h->d_pool64 = d_p64;
+        h->o64_featA = (unsigned)p64.size(); p64.insert(p64.end(), fa.begin(), fa.end());
+        h->o64_featB = (unsigned)p64.size(); p64.insert(p64.end(), fb.begin(), fb.end());
+        h->o64_gasn = (unsigned)p64.size(); p64.insert(p64.end(), gasn.begin(), gasn.end());
+        h->o64_euan = (unsigned)p64.size(); p64.insert(p64.end(), euan.begin(), euan.end());
     }
     P.pot_raw = h->d_pot_raw; P.pf_raw = h->d_pf_raw;
     P.el = d_el; P.featA = d_fa; P.featB = d_fb; P.gas = d_gas; P.eua = d_eua; P.gas_n = d_gasn; P.eua_n = d_euan; P.setc = d_setc;
@@ -1873,31 +2031,41 @@ HotParams make_hot_params(const ptg_env* h)
     F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride;
     F.off_featB = h->off_featB; F.off_gasn = h->off_gasn; F.off_euan = h->off_euan; F.off_sc = h->off_sc; F.off_gas = h->off_gas; F.off_eua = h->off_eua;
     F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.noise_sigma = P.noise_sigma; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
+    F.o64_featA = h->o64_featA; F.o64_featB = h->o64_featB; F.o64_gasn = h->o64_gasn; F.o64_euan = h->o64_euan; F.o64_sc = h->o64_sc;
+    F.rec = P.rec;
+    RewC& c = F.rc;
+    c.c_mol = P.c_mol; c.Hu_ch4 = P.Hu_ch4; c.Hu_h2 = P.Hu_h2; c.dt_cp_evap = P.dt_cp_evap; c.heat_price = P.heat_price; c.o2_price = P.o2_price;
+    c.eeg = P.eeg; c.eta_chp = P.eta_chp; c.one_m_eta_chp = P.one_m_eta_chp; c.M_co2 = P.M_co2; c.M_h2o = P.M_h2o; c.rho = P.rho;
+    c.water_price = P.water_price; c.min_load = P.min_load; c.max_h2 = P.max_h2; c.c_m2 = P.c_m2; c.c_m3 = P.c_m3; c.sim_step_d = P.sim_step_d;
+    c.T_lo = P.T_lo; c.T_rng = P.T_rng; c.h2_lo = P.h2_lo; c.h2_rng = P.h2_rng; c.ch4_lo = P.ch4_lo; c.ch4_rng = P.ch4_rng;
+    c.h2r_lo = P.h2r_lo; c.h2r_rng = P.h2r_rng; c.h2o_lo = P.h2o_lo; c.h2o_rng = P.h2o_rng; c.heat_lo = P.heat_lo; c.heat_rng = P.heat_rng;
     F.recf = P.recf; F.tape = P.tape; F.pool32 = h->d_pool32; F.pool64 = h->d_pool64; F.setc = P.setc; F.argidx = P.argidx;
     F.tabmeta = P.tabmeta; F.ladder = h->d_ladder; F.st_a = P.st_a; F.st_b = P.st_b; F.st_c = P.st_c; F.err = P.err;
     return F;
 }
 
-// the hot kernels apply to float32 outputs, 13-hour look-ahead, a synchronised batch, and steps on which no env terminates
+// the hot kernels apply to a 13-hour look-ahead, a synchronised batch, and steps on which no env terminates
 bool hot_eligible(const ptg_env* h)
 {
-    return h->cfg.out_dtype == PTG_OUT_F32 && h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot &&
-           (unsigned long long)h->n * h->F * 4ull < 0xFFFFFFFFull;
+    // (SB3's flattened rows are float32 by construction: float64 SB3_FLAT rows stay with the generic kernels)
+    const unsigned long long osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && !(h->flat && osz == 8) &&
+           (unsigned long long)h->n * h->F * osz < 0xFFFFFFFFull;
 }
 
 int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
 
-template <int LAY, bool MOD, int NOISE>
-void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, float* obs, float* rew, uint8_t* done)
+template <int LAY, bool MOD, int NOISE, typename OUT>
+void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, OUT* obs, OUT* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
     const dim3 grid(grid_for(h->n, 256)), block(256);
     if (h->profiling) {
         hipEvent_t e0, e1;
         prof_pair(h, e0, e1);
-        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, h->sync_k, obs, rew, done);
+        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, h->sync_k, obs, rew, done);
     } else
-        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
+        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
 }
 
 // Launch geometry of the fused hot rollout.  One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many
@@ -1916,7 +2084,8 @@ PcPlan pc_plan(const ptg_env* h)
     while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block) >= 256) pl.block *= 2;     // block/2 envs per workgroup
     if (h->knob_block) pl.block = h->knob_block;
     const int np = pl.block / 2;
-    if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F) * 4;      // one [64][pitch] float tile per consumer wave (RowTile::PITCH)
+    if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F) * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);      // one [64][pitch] tile per consumer wave (RowTile::PITCH)
+    if (h->cfg.out_dtype == PTG_OUT_F64) pl.fixed += (size_t)(h->P.mod ? 26 : 17) * np * 8;      // the market features' LDS home (k_rollout_pc, MLDS)
     // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
     pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !h->knob_no_lds_lut;
     const size_t avail = pl.lds_max - pl.fixed - (pl.lds_lut ? pl.lut_bytes : 0) - 64;
@@ -1934,7 +2103,8 @@ void launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
     if (h->knob_no_refresh || !h->ref_stream) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
-    const double step_bytes = (double)m * (h->F * 4 + 5);
+    const int osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    const double step_bytes = (double)m * (h->F * osz + osz + 1);
     const double pass_steps = std::max(8.0, 192e6 / step_bytes);
     const bool roll = h->knob_refresh_always || k0 < h->front_horizon;
     const int passes = roll ? std::max(1, (int)std::ceil(tn / pass_steps)) : 1;
@@ -1942,11 +2112,12 @@ void launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
     const unsigned period = (unsigned)std::min(4.0e6, pass_steps * step_us * 100.0);      // ticks of the 100 MHz clock; <= 40 ms
     const long long n16 = (long long)h->rec_total * 4 + ((long long)h->rec_total * 2 + 15) / 16;
     const int grid = (int)std::min<long long>(256, (n16 + 63) / 64);
-    hipLaunchKernelGGL(k_refresh, dim3(grid), dim3(64), 0, h->ref_stream, (const void*)h->P.recf, (const unsigned short*)h->d_rkey, (int)h->rec_total, passes, period);
+    hipLaunchKernelGGL(k_refresh, dim3(grid), dim3(64), 0, h->ref_stream, osz == 8 ? (const void*)h->P.rec : (const void*)h->P.recf,
+                       (const unsigned short*)h->d_rkey, (int)h->rec_total, passes, period);
 }
 
-template <int LAY, bool MOD, int NOISE>
-void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, int T, float* obs, float* rew, uint8_t* done)
+template <int LAY, bool MOD, int NOISE, typename OUT>
+void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, int T, OUT* obs, OUT* rew, uint8_t* done)
 {
     const HotParams hp = make_hot_params(h);
     const PcPlan pl = pc_plan(h);
@@ -1957,8 +2128,8 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
     for (int ts = 0; ts < T; ts += t_cap) {
         const int tn = std::min(t_cap, T - ts);
         const char* a_s = (const char*)actions + (size_t)ts * h->n * asz;
-        float* o_s = obs + (size_t)ts * h->n * h->F;
-        float* r_s = rew + (size_t)ts * h->n;
+        OUT* o_s = obs + (size_t)ts * h->n * h->F;
+        OUT* r_s = rew + (size_t)ts * h->n;
         uint8_t* d_s = done + (size_t)ts * h->n;
         const int k0 = h->sync_k + ts;
         const int vec_rows = (h->n % 4 == 0) && ((uintptr_t)a_s % 16 == 0) && (chunk % 4 == 0);     // whole-row vector loads are aligned
@@ -1970,7 +2141,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
             launch_refresher(h, st, m, tn, k0);
 #define PTG_PC2(LL, FULL)                                                                                             \
     do {                                                                                                              \
-        auto kfn = k_rollout_pc<LAY, MOD, NOISE, LL, FULL>;                                                           \
+        auto kfn = k_rollout_pc<LAY, MOD, NOISE, LL, FULL, OUT>;                                                      \
         static int attr_dev = -1;      /* > 64 KiB of dynamic LDS needs the attribute: once per instantiation and device */ \
         if (attr_dev != h->device) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_dev = h->device; } \
         if (h->profiling) {                                                                                           \
@@ -1989,20 +2160,26 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
     }
 }
 
-#define PTG_HOT_DISPATCH3(FN, LAY_, ...)                                                                 \
+#define PTG_HOT_DISPATCH3(FN, LAY_, OUT_, ...)                                                           \
     do {                                                                                                \
-        if (nm_ == NOISE_TAPE) { if (mod_) FN<LAY_, true, NOISE_TAPE>(__VA_ARGS__); else FN<LAY_, false, NOISE_TAPE>(__VA_ARGS__); }      \
-        else if (nm_ == NOISE_RNG) { if (mod_) FN<LAY_, true, NOISE_RNG>(__VA_ARGS__); else FN<LAY_, false, NOISE_RNG>(__VA_ARGS__); }    \
-        else { if (mod_) FN<LAY_, true, NOISE_NONE>(__VA_ARGS__); else FN<LAY_, false, NOISE_NONE>(__VA_ARGS__); }                        \
+        if (nm_ == NOISE_TAPE) { if (mod_) FN<LAY_, true, NOISE_TAPE, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_TAPE, OUT_>(__VA_ARGS__); }      \
+        else if (nm_ == NOISE_RNG) { if (mod_) FN<LAY_, true, NOISE_RNG, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_RNG, OUT_>(__VA_ARGS__); }    \
+        else { if (mod_) FN<LAY_, true, NOISE_NONE, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_NONE, OUT_>(__VA_ARGS__); }                        \
     } while (0)
-#define PTG_HOT_DISPATCH(FN, ...)                                                                       \
+// obs / rew arrive as void*: the element type is the handle's out_dtype (SB3_FLAT rows are float32 only, see hot_eligible)
+#define PTG_HOT_DISPATCH(FN, H_, ST_, A_, KIND_, CNT_ARGS_, OBS_, REW_, DONE_)                           \
     do {                                                                                                \
-        const int nm_ = noise_mode(h);                                                                  \
-        const bool mod_ = h->P.mod != 0;                                                                \
-        if (h->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, __VA_ARGS__);                           \
-        else if (h->flat) PTG_HOT_DISPATCH3(FN, PTG_OBS_SB3_FLAT, __VA_ARGS__);                         \
-        else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, __VA_ARGS__);                                     \
+        const int nm_ = noise_mode(H_);                                                                 \
+        const bool mod_ = (H_)->P.mod != 0;                                                             \
+        if ((H_)->cfg.out_dtype == PTG_OUT_F64) {                                                       \
+            if ((H_)->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_); \
+            else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_);               \
+        } else if ((H_)->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);  \
+        else if ((H_)->flat) PTG_HOT_DISPATCH3(FN, PTG_OBS_SB3_FLAT, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);       \
+        else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);                      \
     } while (0)
+#define PTG_NOARG
+#define PTG_COMMA_ARG(x) , x
 
 hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
@@ -2160,6 +2337,14 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         h->d_pool32 = d_pool;
         P.featA32 = d_pool; P.featB32 = d_pool + h->off_featB; P.gas_n32 = d_pool + h->off_gasn; P.eua_n32 = d_pool + h->off_euan;
         pool.clear(); pool.shrink_to_fit();
+        std::vector<double>& p64 = h->pool64_host;
+        h->o64_sc = (unsigned)p64.size();
+        for (size_t q = 0; q < sc.size(); q++) { p64.push_back(sc[q].x); p64.push_back(sc[q].y); }
+        p64.resize(p64.size() + 16, 0.0);
+        double* d_p64;
+        if ((rc = dev_upload(h, &d_p64, p64.data(), p64.size()))) return fail(rc);
+        h->d_pool64 = d_p64;
+        p64.clear(); p64.shrink_to_fit();
     }
     // fast-path records: reward coefficients per window start (k_build_fast)
     {
@@ -2394,7 +2579,7 @@ int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev
     hipStream_t st = as_stream(stream);
     const int k_term = h->cfg.eps_sim_steps - 6;               // the step taken at k == k_term terminates (:508-511)
     if (hot_eligible(h) && !info_dev && h->sync_k != k_term) {
-        PTG_HOT_DISPATCH(launch_step_hot, h, st, actions_dev, action_kind, (float*)obs_dev, (float*)rew_dev, done_dev);
+        PTG_HOT_DISPATCH(launch_step_hot, h, st, actions_dev, action_kind, PTG_NOARG, obs_dev, rew_dev, done_dev);
         h->sync_k += 1;
         return launch_check(h, "k_step_hot");
     }
@@ -2425,7 +2610,7 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
         int rc = 0, cnt;
         if (hot_eligible(h) && h->sync_k != k_term) {
             cnt = std::min(n_steps - t0, k_term - h->sync_k);
-            PTG_HOT_DISPATCH(launch_rollout_hot, h, st, a_t, action_kind, cnt, (float*)o_t, (float*)r_t, d_t);
+            PTG_HOT_DISPATCH(launch_rollout_hot, h, st, a_t, action_kind, PTG_COMMA_ARG(cnt), o_t, r_t, d_t);
             rc = launch_check(h, "k_rollout_pc");
             h->sync_k += cnt;
         } else if (h->sync_k >= 0) {                            // the terminating step of a synchronised batch

@@ -18,13 +18,13 @@ dev = torch.device("cuda", 0)
 spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=32)
 first_ptr, stride = ptg_dist.episode_plan(n, 1, 0)
 for rep in range(4):
-    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout=layout)
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=os.environ.get("TS_DTYPE", "float32"), obs_layout=layout)
     eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
     eng.set_noise_rng(seed=20250614)
     actions = sticky_actions_device(W + K * (M + 1), n, seed=1234 + rep, device=dev, p_switch=1.0 / 12.0)
     F = eng.obs_dim
-    obs = torch.zeros((K, F, n) if eng.feature_major else (K, n, F), dtype=torch.float32, device=dev)
-    rew = torch.zeros((K, n), dtype=torch.float32, device=dev)
+    obs = torch.zeros((K, F, n) if eng.feature_major else (K, n, F), dtype=eng.out_dtype, device=dev)
+    rew = torch.zeros((K, n), dtype=eng.out_dtype, device=dev)
     done = torch.zeros((K, n), dtype=torch.uint8, device=dev)
     eng.reset()
     eng.rollout(actions[:W], obs[:W], rew[:W], done[:W])

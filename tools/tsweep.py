@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 layout = os.environ.get("TS_LAYOUT", "feature")
 spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=32)
 first_ptr, stride = ptg_dist.episode_plan(n, 1, 0)
-eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout=layout)
+eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=os.environ.get("TS_DTYPE", "float32"), obs_layout=layout)
 eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
 eng.set_noise_rng(seed=20250614)
 TS = [int(x) for x in os.environ.get("TS_T", "1,2,5,10,20,25,50,100,200,400").split(",")]
@@ -24,8 +24,8 @@ REPS = int(os.environ.get("TS_REPS", "6"))
 TMAX = max(TS)
 actions = sticky_actions_device(600 + TMAX, n, seed=1234, device=dev, p_switch=1.0 / 12.0)
 F = eng.obs_dim
-obs = torch.zeros((TMAX, F, n) if eng.feature_major else (TMAX, n, F), dtype=torch.float32, device=dev)
-rew = torch.zeros((TMAX, n), dtype=torch.float32, device=dev)
+obs = torch.zeros((TMAX, F, n) if eng.feature_major else (TMAX, n, F), dtype=eng.out_dtype, device=dev)
+rew = torch.zeros((TMAX, n), dtype=eng.out_dtype, device=dev)
 done = torch.zeros((TMAX, n), dtype=torch.uint8, device=dev)
 eng.reset()
 eng.rollout(actions[:400], obs[:400] if TMAX >= 400 else None, None, None)      # stationary state mix
