@@ -20,13 +20,14 @@
 #ifndef PTG_ENV_H
 #define PTG_ENV_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PTG_ABI_VERSION 3   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile* */
+#define PTG_ABI_VERSION 3   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -169,6 +170,21 @@ int ptg_rollout(ptg_env* env, const void* actions_dev, int action_kind, int n_st
  * collects into its stats array (src/rl_utils.py:528-565).  Runs the generic step kernel T times. */
 int ptg_rollout_info(ptg_env* env, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
                      uint8_t* done_dev, double* info_dev, void* stream);
+/* One vector step with HOST buffers in and out -- the call behind VecEnv.step_wait.  Replaces DummyVecEnv.step_wait's loop
+ * `for env_idx: obs, rew, terminated, truncated, info = envs[env_idx].step(actions[env_idx])` + `_save_obs` (SB3 dummy_vec_env.py,
+ * as the reference builds it in src/rl_utils.py:448-453).
+ *   actions_host  [N] of action_kind
+ *   out_host      one block: observations [N][F] (layout per cfg.obs_layout) at offset 0, rewards [N] at off_rew, done flags
+ *                 [N] uint8 at off_done (ptg_host_layout gives the offsets and the total size; all 16-byte aligned)
+ *   final_obs_host [N][F] (nullable): rows of the envs whose episode ended = terminal observation; written only when *n_done > 0
+ *   info_host     [N][24] float64 (nullable; needs cfg.train_or_eval = 1)
+ *   n_done        number of envs whose episode ended on this step
+ * Synchronises `stream` before it returns and reports kernel-flagged errors (PTG_E_ACTION / PTG_E_RANGE) like ptg_sync.
+ * When the blocks are pinned, device-mapped host memory (hipHostMalloc, torch pin_memory) and small (<= 256 KiB in all) the
+ * kernels read and write them in place -- no copies; otherwise the library stages through device buffers with one copy each way. */
+int ptg_host_layout(const ptg_env* env, size_t* off_rew, size_t* off_done, size_t* total);
+int ptg_step_host(ptg_env* env, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
+                  int* n_done, void* stream);
 /* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
  * per-launch timing); negative PTG_E_* on a bad argument. */
 int ptg_rollout_launches(ptg_env* env, int n_steps);

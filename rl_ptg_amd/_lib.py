@@ -58,7 +58,7 @@ STATE_FIELDS = {"meth_state": 0, "i": 1, "j": 2, "k": 3, "hot_cold": 4, "standby
 
 EXPORTS = ["ptg_abi_version", "ptg_create", "ptg_destroy", "ptg_num_envs", "ptg_obs_dim", "ptg_last_error",
            "ptg_set_market_assignment", "ptg_set_episode_plan", "ptg_set_noise_tape", "ptg_set_noise_rng", "ptg_set_global_env_offset", "ptg_fill_noise_tape",
-           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_profile", "ptg_profile_read", "ptg_sync", "ptg_get_state", "ptg_set_state",
+           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_profile", "ptg_profile_read", "ptg_sync", "ptg_get_state", "ptg_set_state",
            "ptg_finished_episodes", "ptg_vn_init", "ptg_vn_batch_moments", "ptg_vn_apply", "ptg_vn_get", "ptg_vn_set",
            "ptg_debug_get_index_lut", "ptg_debug_window_record"]
 
@@ -110,6 +110,8 @@ def lib():
     L.ptg_rollout.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.ptg_rollout_info.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.ptg_rollout_launches.argtypes = [vp, C.c_int]
+    L.ptg_step_host.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_int), vp]
+    L.ptg_host_layout.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ptg_profile.argtypes = [vp, C.c_int]
     L.ptg_profile_read.argtypes = [vp, dp, C.c_int, C.POINTER(C.c_int)]
     L.ptg_sync.argtypes = [vp, vp]

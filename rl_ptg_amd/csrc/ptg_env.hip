@@ -106,7 +106,8 @@ struct DevParams {
     // finished-episode list
     double* fin_ret; int* fin_len; int* fin_env; int* fin_count; int fin_cap;
     const int* cmap; int q_stat;          // SB3_FLAT layout: canonical column -> flat column; canonical index of METH_STATUS (else cmap = null)
-    int* err;
+    int* err;                             // [2] in pinned HOST memory: {invalid action seen, price index out of range}; kernels store 1 (plain
+                                          // stores of a constant need no atomic), the host reads it after a stream synchronise -- no copy
 };
 
 __device__ __forceinline__ int part_tid(int p) { return p == 0 ? PTG_T_OP1_START_P : 7 + p; }          // 5, 8..12
@@ -540,7 +541,7 @@ __device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta
     const int secs = k1 * P.sim_step;
     int H = R.b.act_d * 24 + secs / 3600, D = R.b.act_d + secs / 86400;
     if (H + P.PA > P.n_hours || D + 2 > P.n_days || H < 0 || D < 0) {
-        atomicOr(P.err, 2);
+        P.err[1] = 1;
         H = max(0, min(H, P.n_hours - P.PA)); D = max(0, min(D, P.n_days - 2));
     }
     const double el = P.el[(size_t)mset * P.hstride + H];
@@ -646,7 +647,7 @@ k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT
     if (live) {
         const int act = decode_action(actions, action_kind, e, (R.a.flags >> 12) & 7);
         if (act < 0) {
-            atomicOr(P.err, 1);
+            P.err[0] = 1;
             rew[e] = (OUT)NAN;
             done[e] = 0;
         } else {
@@ -1006,7 +1007,7 @@ __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, c
     int H = R.act_d * 24 + hs, D = R.act_d + ds;
     const bool oob = (H + 13 > P.n_hours) | (D + 2 > P.n_days) | (H < 0) | (D < 0);
     if (__ballot(oob)) {
-        if (oob) { atomicOr(P.err, 2); H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
+        if (oob) { P.err[1] = 1; H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
     }
     const unsigned hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u, db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
     Q.hb4 = hb4; Q.db4 = db4; Q.kk8 = (unsigned)min(k1, P.eps_sim_steps) * 8u;
@@ -1155,7 +1156,7 @@ __device__ __forceinline__ int hot_decode(int actk, const HotParams& P, int raw_
     const int prev = (flags >> 12) & 7;
     if (actk == PTG_ACT_F32) return decode_continuous(raw_f, prev);
     const bool bad = (raw_i < -5) | (raw_i > 4);
-    if (__ballot(bad)) { if (bad) atomicOr(P.err, 1); }
+    if (__ballot(bad)) { if (bad) P.err[0] = 1; }
     return bad ? prev : (raw_i < 0 ? raw_i + 5 : raw_i);
 }
 
@@ -1420,7 +1421,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         if (actk == PTG_ACT_F32) stage(std::integral_constant<int, PTG_ACT_F32>{});
         else if (actk == PTG_ACT_I64) stage(std::integral_constant<int, PTG_ACT_I64>{});
         else stage(std::integral_constant<int, PTG_ACT_I32>{});
-        if (__ballot(bad_any)) { if (bad_any) atomicOr(P.err, 1); }
+        if (__ballot(bad_any)) { if (bad_any) P.err[0] = 1; }
     }
     hot_stage_lds(P, L);
     if (LDSLUT) {                       // 16-byte pieces, four loads in flight per lane (the lookup is padded to whole pieces)
@@ -1444,7 +1445,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         int H = R.act_d * 24 + secs / 3600, D = R.act_d + secs / 86400;
         const bool oob = (H + 13 > P.n_hours) | (D + 2 > P.n_days) | (H < 0) | (D < 0);
         if (__ballot(oob)) {
-            if (oob) { atomicOr(P.err, 2); H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
+            if (oob) { P.err[1] = 1; H = max(0, min(H, P.n_hours - 13)); D = max(0, min(D, P.n_days - 2)); }
         }
         hb4 = (mset * (unsigned)P.hstride + (unsigned)H) * 4u;
         db4 = (mset * (unsigned)P.dstride + (unsigned)D) * 4u;
@@ -1785,6 +1786,10 @@ struct ptg_env {
     bool knob_no_hot = false, knob_no_lds_lut = false, knob_no_refresh = false, knob_refresh_always = false;
     int front_horizon = 0;       // steps after a synchronised reset during which the table refresher keeps rolling (k_refresh)
     hipStream_t ref_stream = nullptr;
+    int* err_host = nullptr;     // DevParams::err as the host sees it
+    // ptg_step_host: device staging for batches too large for zero-copy, and the classification of the caller's buffers
+    void *hs_act = nullptr, *hs_out = nullptr, *hs_final = nullptr; double* hs_info = nullptr;
+    const void* hs_seen[4] = {nullptr, nullptr, nullptr, nullptr}; void* hs_dev[4] = {nullptr, nullptr, nullptr, nullptr}; bool hs_zero_copy = false;
     int knob_chunk = 65536, knob_block = 0;
     // per-launch timing (ptg_profile): kernel-attached start / stop events of the launches since profiling was switched on
     bool profiling = false;
@@ -2183,17 +2188,22 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
 
 hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
-int collect_error(ptg_env* h, hipStream_t st)
+int check_error_flags(ptg_env* h)          // after the stream has been synchronised
 {
-    int flag = 0;
-    HIP_TRY(h, hipMemcpyAsync(&flag, h->P.err, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
-    if (flag) {
-        HIP_TRY(h, hipMemsetAsync(h->P.err, 0, sizeof(int), st));
-        if (flag & 1) return set_err(h, PTG_E_ACTION, "a discrete action outside [-5, 4] was passed (the reference raises IndexError)");
+    volatile int* e = h->err_host;
+    const int bad_action = e[0], bad_range = e[1];
+    if (bad_action | bad_range) {
+        e[0] = 0; e[1] = 0;
+        if (bad_action) return set_err(h, PTG_E_ACTION, "a discrete action outside [-5, 4] was passed (the reference raises IndexError)");
         return set_err(h, PTG_E_RANGE, "a price index left the market series (episode longer than the data)");
     }
     return 0;
+}
+
+int collect_error(ptg_env* h, hipStream_t st)
+{
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return check_error_flags(h);
 }
 
 }  // namespace
@@ -2218,6 +2228,8 @@ void ptg_destroy(ptg_env* env)
     if (env->vn_den) (void)hipFree(env->vn_den);
     if (env->vn_moments) (void)hipFree(env->vn_moments);
     if (env->ref_stream) { (void)hipStreamSynchronize(env->ref_stream); (void)hipStreamDestroy(env->ref_stream); }
+    if (env->err_host) (void)hipHostFree(env->err_host);
+    for (void* q : {env->hs_act, env->hs_out, env->hs_final, (void*)env->hs_info}) if (q) (void)hipFree(q);
     for (auto* v : {&env->prof_used, &env->prof_free})
         for (auto& p : *v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete env;
@@ -2365,9 +2377,16 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         return fail(rc);
     P.fin_cap = std::max(2 * n_envs, 1024);
     if ((rc = dev_alloc(h, &P.fin_ret, P.fin_cap)) || (rc = dev_alloc(h, &P.fin_len, P.fin_cap)) ||
-        (rc = dev_alloc(h, &P.fin_env, P.fin_cap)) || (rc = dev_alloc(h, &P.fin_count, 1)) || (rc = dev_alloc(h, &P.err, 1)))
+        (rc = dev_alloc(h, &P.fin_env, P.fin_cap)) || (rc = dev_alloc(h, &P.fin_count, 1)))
         return fail(rc);
-    if (hipMemset(P.fin_count, 0, sizeof(int)) != hipSuccess || hipMemset(P.err, 0, sizeof(int)) != hipSuccess) {
+    {   // the error words live in pinned host memory the kernels can write (see DevParams::err)
+        void* dp = nullptr;
+        if (hipHostMalloc((void**)&h->err_host, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, h->err_host, 0) != hipSuccess) { set_err(h, PTG_E_HIP, "hipHostMalloc of the error words failed"); return fail(PTG_E_HIP); }
+        h->err_host[0] = 0; h->err_host[1] = 0;
+        P.err = (int*)dp;
+    }
+    if (hipMemset(P.fin_count, 0, sizeof(int)) != hipSuccess) {
         set_err(h, PTG_E_HIP, "hipMemset failed");
         return fail(PTG_E_HIP);
     }
@@ -2660,6 +2679,80 @@ int ptg_rollout_launches(ptg_env* h, int n_steps)
         }
     }
     return launches;
+}
+
+// ---- the SB3-facing form of a step: host buffers in, host buffers out, one call ---------------------------------------
+int ptg_host_layout(const ptg_env* h, size_t* off_rew, size_t* off_done, size_t* total)
+{
+    if (!h) return PTG_E_INVALID;
+    const size_t osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    const size_t o_rew = ((size_t)h->n * h->F * osz + 15) / 16 * 16, o_done = (o_rew + (size_t)h->n * osz + 15) / 16 * 16;
+    if (off_rew) *off_rew = o_rew;
+    if (off_done) *off_done = o_done;
+    if (total) *total = (o_done + (size_t)h->n + 15) / 16 * 16;
+    return 0;
+}
+
+int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
+                  int* n_done, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!actions_host || !out_host || !n_done) return set_err(h, PTG_E_INVALID, "ptg_step_host: null buffer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = as_stream(stream);
+    const size_t osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4, asz = action_kind == PTG_ACT_I64 ? 8 : 4;
+    size_t o_rew, o_done, total;
+    ptg_host_layout(h, &o_rew, &o_done, &total);
+    const size_t final_bytes = (size_t)h->n * h->F * osz, info_bytes = (size_t)h->n * PTG_N_INFO * sizeof(double);
+    // Small batches: the kernels read the actions from and write their outputs to the caller's pinned buffers directly (zero
+    // copy: no DMA descriptors, one launch + one synchronise per step).  Large ones: device staging, one copy each way.
+    const void* ptrs[4] = {actions_host, out_host, final_obs_host, info_host};
+    if (memcmp(ptrs, h->hs_seen, sizeof ptrs) != 0) {          // a new set of buffers: classify once
+        bool mapped = total + final_bytes <= (256u << 10);
+        for (int q = 0; q < 4 && mapped; q++) {
+            h->hs_dev[q] = nullptr;
+            if (!ptrs[q]) continue;
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, ptrs[q]) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer) { (void)hipGetLastError(); mapped = false; }
+            else h->hs_dev[q] = at.devicePointer;
+        }
+        h->hs_zero_copy = mapped;
+        memcpy(h->hs_seen, ptrs, sizeof ptrs);
+        if (!mapped) {
+            if (!h->hs_act) HIP_TRY(h, hipMalloc(&h->hs_act, (size_t)h->n * 8));
+            if (!h->hs_out) HIP_TRY(h, hipMalloc(&h->hs_out, total));
+            if (!h->hs_final) HIP_TRY(h, hipMalloc(&h->hs_final, final_bytes));
+            if (info_host && !h->hs_info) HIP_TRY(h, hipMalloc((void**)&h->hs_info, info_bytes));
+        }
+    }
+    const bool zc = h->hs_zero_copy;
+    const void* d_act = zc ? h->hs_dev[0] : h->hs_act;
+    char* d_out = (char*)(zc ? h->hs_dev[1] : h->hs_out);
+    void* d_final = final_obs_host ? (zc ? h->hs_dev[2] : h->hs_final) : nullptr;
+    double* d_info = info_host ? (zc ? (double*)h->hs_dev[3] : h->hs_info) : nullptr;
+    if (!zc) HIP_TRY(h, hipMemcpyAsync(h->hs_act, actions_host, (size_t)h->n * asz, hipMemcpyHostToDevice, st));
+    int rc = ptg_step(h, d_act, action_kind, d_out, d_out + o_rew, (uint8_t*)(d_out + o_done), d_final, d_info, stream);
+    if (rc) return rc;
+    if (!zc) {
+        HIP_TRY(h, hipMemcpyAsync(out_host, h->hs_out, total, hipMemcpyDeviceToHost, st));
+        if (info_host) HIP_TRY(h, hipMemcpyAsync(info_host, h->hs_info, info_bytes, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if ((rc = check_error_flags(h))) return rc;
+    const uint8_t* dn = (const uint8_t*)out_host + o_done;
+    int cnt = 0;
+    size_t e = 0;
+    for (; e + 8 <= (size_t)h->n; e += 8) {                     // done flags are 0 / 1 bytes: sum eight at a time
+        uint64_t w; memcpy(&w, dn + e, 8);
+        if (w) cnt += __builtin_popcountll(w);
+    }
+    for (; e < (size_t)h->n; e++) cnt += dn[e] != 0;
+    if (cnt && !zc && final_obs_host) {                         // rare: the terminal observations of the episodes that just ended
+        HIP_TRY(h, hipMemcpyAsync(final_obs_host, h->hs_final, final_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    *n_done = cnt;
+    return 0;
 }
 
 // ---- VecNormalize(norm_obs=False) on the device ---------------------------------------------------------------------

@@ -153,6 +153,7 @@ class HipEngine:
     def set_noise_tape(self, tape):
         if tape is None:
             self._chk(self._L.ptg_set_noise_tape(self._h, None, 0))
+            self._noise_cfg = {"mode": "none"}
             return
         a = np.ascontiguousarray(tape, dtype=np.float64)
         assert a.ndim == 2 and a.shape[0] == self.n
@@ -166,6 +167,7 @@ class HipEngine:
 
     def set_global_env_offset(self, offset):
         self._chk(self._L.ptg_set_global_env_offset(self._h, int(offset)))
+        self._env_offset = int(offset)
 
     def fill_noise_tape(self, seed, per_env_len):
         self._chk(self._L.ptg_fill_noise_tape(self._h, int(seed) & (2 ** 64 - 1), int(per_env_len), self._stream()))
@@ -276,14 +278,16 @@ class HipEngine:
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):
         """Everything a resumed run needs beyond the constructor arguments and the episode plan: every per-env state field,
-        the noise source and -- if started -- the reward normaliser (NumPy arrays / plain numbers; synchronises)."""
-        sd = {"fields": {k: self.get_state(k) for k in _lib.STATE_FIELDS}, "n": self.n}
+        the noise source, the global env offset and -- if started -- the reward normaliser with its hyper-parameters (NumPy arrays /
+        plain numbers; synchronises).  Not included: the list of finished episodes not yet collected (ptg_finished_episodes)."""
+        sd = {"fields": {k: self.get_state(k) for k in _lib.STATE_FIELDS}, "n": self.n,
+              "env_offset": self.__dict__.get("_env_offset", 0)}       # keys the in-kernel RNG streams (global env index)
         sd["noise"] = dict(self.__dict__.get("_noise_cfg", {"mode": "none"}))
         if sd["noise"].get("mode") == "tape":
             sd["noise"]["tape"] = self.get_noise_tape(sd["noise"]["per_env_len"])
         try:
             st, ret = self.vn_get()
-            sd["vn"] = {"stats": st, "returns": ret}
+            sd["vn"] = {"stats": st, "returns": ret, "hyper": dict(self.__dict__.get("_vn_hyper", {}))}
         except PtgError:
             pass
         return sd
@@ -291,6 +295,8 @@ class HipEngine:
     def load_state_dict(self, sd):
         """Inverse of state_dict() on an engine built with the same arguments (reset() first, then the episode plan)."""
         assert sd["n"] == self.n
+        if "env_offset" in sd:
+            self.set_global_env_offset(sd["env_offset"])
         nz = sd.get("noise", {})
         if nz.get("mode") == "rng":
             self.set_noise_rng(nz["seed"])
@@ -301,10 +307,14 @@ class HipEngine:
                 self.set_state(k, v)
         self.set_state("k", sd["fields"]["k"])              # last: equal step counts mark the batch as synchronised again
         if "vn" in sd:
-            try:
-                self.vn_get()
-            except PtgError:
-                self.vn_init()
+            hyper = sd["vn"].get("hyper") or {}
+            if hyper and hyper != self.__dict__.get("_vn_hyper"):
+                self.vn_init(**hyper)                           # the checkpoint's gamma / epsilon / clip_reward
+            else:
+                try:
+                    self.vn_get()
+                except PtgError:
+                    self.vn_init()
             self.vn_set(stats=sd["vn"]["stats"], returns=sd["vn"]["returns"])
 
     def finished_episodes(self, cap=None):
@@ -322,6 +332,7 @@ class HipEngine:
     def vn_init(self, gamma=0.99, epsilon=1e-8, clip_reward=10.0):
         """Start reward normalisation as the reference wraps its envs (src/rl_utils.py:453, SB3 defaults)."""
         self._chk(self._L.ptg_vn_init(self._h, float(gamma), float(epsilon), float(clip_reward)))
+        self._vn_hyper = {"gamma": float(gamma), "epsilon": float(epsilon), "clip_reward": float(clip_reward)}
 
     def vn_normalize(self, rew, done, training=True, out=None, group=None):
         """Normalise a [T, N] (or [N]) reward tensor in place of VecNormalize.step_wait: advances the discounted returns,

@@ -43,13 +43,59 @@ except Exception:
     _VecEnvBase = object
 
 
+_INFO_INT = frozenset(("step", "Meth_State", "Meth_Hot_Cold"))
+_INFO_POS = {k: q for q, k in enumerate(INFO_KEYS)}
+
+
+class _InfoRow(dict):
+    """info dict of one env of a LARGE eval batch: the 24 reference keys are read on demand from the step's info matrix (building
+    65 536 x 24-entry dicts per step is the O(N) Python loop SURVEY.md section 7 warns about); keys stored explicitly (episode,
+    terminal_observation, ...) behave as in a plain dict.  Reads reflect the latest step of the owning PtGVecEnv."""
+    __slots__ = ("_own", "_e")
+
+    def __init__(self, owner, e):
+        super().__init__()
+        self._own, self._e = owner, e
+
+    def __missing__(self, k):
+        q = _INFO_POS[k]
+        v = self._own._info_cur[self._e, q]
+        return int(v) if k in _INFO_INT else (ACTIONS[int(v)] if k == "Meth_Action" else float(v))
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or (k in _INFO_POS and self._own._info_cur is not None)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def keys(self):
+        return list(INFO_KEYS) + [k for k in dict.keys(self)]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(INFO_KEYS) + dict.__len__(self)
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 class PtGVecEnv(_VecEnvBase):
     metadata = {"render_modes": ["None"]}
+    OBS_RING = 4            # large batches: step() hands out views of a ring of pinned blocks (see _setup_host)
+    EAGER_INFO_MAX = 64     # eval batches up to this size get plain 24-key info dicts every step, larger ones _InfoRow views
 
     def __init__(self, dict_input, n_envs, train_or_eval="train", seed=None, device=0, out_dtype="float64", obs_layout="row",
                  noise="numpy", noise_tape_len=256, world_size=1, rank=0, render_mode="None", engine_cls=HipEngine,
                  norm_reward=False, gamma=0.99, epsilon=1e-8, clip_reward=10.0):
         spec = dict_input if isinstance(dict_input, EnvSpec) else EnvSpec.from_dict_input(dict_input, train_or_eval)
+        want = {"train": 0, "eval": 1}[train_or_eval]
+        if int(spec.consts.get("train_or_eval", want)) != want:      # a prepared EnvSpec used for the other mode: the argument wins
+            spec = EnvSpec(dict(spec.consts, train_or_eval=want), spec.tables, spec.markets, spec.eps_ind)
         self.spec = spec
         self.train_or_eval = train_or_eval
         self.raw_modified = "mod" if spec.consts["raw_modified"] else "raw"
@@ -68,6 +114,8 @@ class PtGVecEnv(_VecEnvBase):
         # DummyVecEnv order: n_total constructions consume eps_ind[0:n_total]; the first vector reset takes eps_ind[n_total + e]
         self.engine.set_episode_plan(spec.eps_ind, first_ptr=self.n_total + self.env_offset, stride=self.n_total)
         self._cols, self._F = obs_columns(self.raw_modified, spec.consts["price_ahead"])
+        keys = list(self.observation_space.spaces) if hasattr(self.observation_space, "spaces") else list(self._cols)
+        self._key_slices = [(k, self._cols[k]) for k in keys]
         self.noise_mode = noise
         self.noise_sigma = float(spec.consts["noise"])
         self._tape_len = int(noise_tape_len)
@@ -88,6 +136,7 @@ class PtGVecEnv(_VecEnvBase):
         self._old_reward = None
         if self.norm_reward:
             self.engine.vn_init(gamma=gamma, epsilon=epsilon, clip_reward=clip_reward)
+        self._setup_host()
 
     def get_original_reward(self):
         """Unnormalised rewards of the last step (VecNormalize.get_original_reward)."""
@@ -129,26 +178,90 @@ class PtGVecEnv(_VecEnvBase):
         self._apply_seed(seed)
         return [None if seed is None else seed + self.env_offset + e for e in range(self.num_envs)]
 
+    # ------------------------------------------------------------------ host buffers
+    def _setup_host(self):
+        """Pinned host blocks for ptg_step_host (include/ptg_env.h): actions in, [obs | rewards | dones] out, laid out by the
+        library.  Small batches (<= 64 KiB per step) get ONE block -- the kernels write it in place over PCIe -- and every step()
+        hands out fresh copies, like DummyVecEnv.  Large batches rotate through a ring of OBS_RING blocks and hand out VIEWS: an
+        observation stays valid until step() has been called OBS_RING - 1 more times (SB3 keeps `_last_obs` across exactly one
+        step()); copying 9-18 MB per step would cost more than the step."""
+        import ctypes as C
+        import torch
+        eng = self.engine
+        o_rew, o_done, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        eng._chk(eng._L.ptg_host_layout(eng._h, C.byref(o_rew), C.byref(o_done), C.byref(total)))
+        self._off_rew, self._off_done, self._blk_bytes = o_rew.value, o_done.value, total.value
+        n, F = self.num_envs, eng.obs_dim
+        self._odt = np.float64 if eng.out_dtype == torch.float64 else np.float32
+        self._copy_out = total.value <= (64 << 10)
+        k = 1 if self._copy_out else self.OBS_RING
+
+        def pinned(nbytes):
+            try:
+                t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:                           # pinning refused: the library stages through device buffers
+                t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8)
+            self._keep.append(t)
+            return t.numpy()
+        self._keep = []
+        self._blk = [pinned(total.value) for _ in range(k)]
+        self._blk_ptr = [C.c_void_p(b.ctypes.data) for b in self._blk]
+        self._views = [self._carve(b) for b in self._blk]
+        self._slot = 0
+        adt = np.float32 if self.action_type == "continuous" else np.int32
+        self._act_buf = pinned(n * 4).view(adt)[:n]
+        self._act_ptr = C.c_void_p(self._act_buf.ctypes.data)
+        self._act_kind = 1 if self.action_type == "continuous" else 0      # PTG_ACT_F32 / PTG_ACT_I32
+        self._final = pinned(n * F * np.dtype(self._odt).itemsize).view(self._odt)
+        self._final_ptr = C.c_void_p(self._final.ctypes.data)
+        self._final_mat = self._final.reshape(F, n).T if eng.feature_major else self._final.reshape(n, F)
+        self._info_host, self._info_ptr = None, None
+        if eng.eval_mode:
+            self._info_host = pinned(n * 24 * 8).view(np.float64)[:n * 24].reshape(n, 24)
+            self._info_ptr = C.c_void_p(self._info_host.ctypes.data)
+        self._n_done = C.c_int(0)
+        self._n_done_ref = C.byref(self._n_done)
+        self._stream_ptr = eng._stream()
+        # infos: N persistent dicts, replaced only for envs whose episode ended (and put back empty on the next step)
+        self._infos = [{} for _ in range(n)]
+        self._dirty = []
+        self._lazy_info = eng.eval_mode and n > self.EAGER_INFO_MAX
+        if self._lazy_info:
+            self._infos = [_InfoRow(self, e) for e in range(n)]
+        self._info_cur = None
+
+    def _carve(self, blk):
+        """(obs matrix [N, F] view, rewards view, dones view) of one host block"""
+        n, F = self.num_envs, self.engine.obs_dim
+        nb = n * F * np.dtype(self._odt).itemsize
+        flat = blk[:nb].view(self._odt)
+        mat = flat.reshape(F, n).T if self.engine.feature_major else flat.reshape(n, F)
+        rew = blk[self._off_rew:self._off_rew + n * np.dtype(self._odt).itemsize].view(self._odt)
+        done = blk[self._off_done:self._off_done + n]
+        return mat, rew, done
+
     # ------------------------------------------------------------------ observations
-    def _obs_dict(self, mat):
-        """[N, F] float matrix (reference dict order) -> dict keyed like observation_space, dtypes of the declared spaces"""
+    def _obs_dict(self, mat, copy=True):
+        """[N, F] matrix (reference dict order) -> dict keyed like observation_space.  copy=False: column views of `mat`
+        (METH_STATUS is always a new int64 array).  Element type = the engine's out_dtype (float64 by default, as declared)."""
         out = {}
-        for k, sl in self._cols.items():
+        for k, sl in self._key_slices:
             if k == "METH_STATUS":
                 out[k] = np.rint(mat[:, sl.start]).astype(np.int64)
             else:
-                out[k] = np.ascontiguousarray(mat[:, sl], dtype=np.float64)
-        return {k: out[k] for k in self.observation_space.spaces} if hasattr(self.observation_space, "spaces") else out
+                out[k] = np.array(mat[:, sl], copy=True) if copy else mat[:, sl]
+        return out
 
     def _obs_row_dict(self, row):
         d = self._obs_dict(row[None, :])
         return {k: (v[0] if k != "METH_STATUS" else int(v[0])) for k, v in d.items()}
 
-    def _info_dict(self, row):
+    @staticmethod
+    def _info_dict(row):
         d = {}
         for q, k in enumerate(INFO_KEYS):
             v = row[q]
-            if k in ("step", "Meth_State", "Meth_Hot_Cold"):
+            if k in _INFO_INT:
                 d[k] = int(v)
             elif k == "Meth_Action":
                 d[k] = ACTIONS[int(v)]
@@ -177,61 +290,133 @@ class PtGVecEnv(_VecEnvBase):
         self._ep_start[:] = time.time()
         self._needs_reset = False
         self.reset_infos = [{} for _ in range(self.num_envs)]
+        if self.norm_reward:                                  # VecNormalize.reset(): self.returns = np.zeros(self.num_envs)
+            self.engine.vn_set(returns=np.zeros(self.num_envs))
         return self._obs_dict(obs)
 
     def step_async(self, actions):
         a = np.asarray(actions)
         if self.action_type == "continuous":
-            a = a.reshape(self.num_envs, -1)[:, 0].astype(np.float32)
+            a = a.reshape(self.num_envs, -1)[:, 0]
         else:
-            a = a.reshape(self.num_envs).astype(np.int32)
-        self._actions = a
+            a = a.reshape(self.num_envs)
+        np.copyto(self._act_buf, a, casting="unsafe")         # into the pinned block the kernel (or the H2D copy) reads
+        self._actions = self._act_buf
+
+    def _finish_infos(self, dones, n_done, final_mat):
+        """Monitor / DummyVecEnv conventions for the envs whose episode ended; everything else keeps its persistent entry."""
+        infos = self._infos
+        if self._dirty:                                       # last step's finished envs: back to a plain entry
+            for e in self._dirty:
+                infos[e] = _InfoRow(self, e) if self._lazy_info else {}
+            self._dirty = []
+        if self.engine.eval_mode:
+            if self._lazy_info:
+                self._info_cur = self._info_host.copy()       # rows are read through _InfoRow on demand
+            else:
+                info = self._info_host
+                for e in range(self.num_envs):
+                    infos[e] = self._info_dict(info[e])
+        if n_done:
+            r, l, ids = self.engine.finished_episodes()
+            now = time.time()
+            ep = {int(i): (float(rr), int(ll)) for rr, ll, i in zip(r, l, ids)}
+            for e in np.nonzero(dones)[0]:
+                d = dict(infos[e]) if self.engine.eval_mode else {}
+                d["terminal_observation"] = self._obs_row_dict(final_mat[e])
+                d["TimeLimit.truncated"] = False
+                rr, ll = ep.get(int(e), (float("nan"), 0))
+                d["episode"] = {"r": round(rr, 6), "l": ll, "t": round(now - self._t0, 6)}
+                infos[e] = d
+                self._ep_start[e] = now
+                self._dirty.append(int(e))
+        return infos
 
     def step_wait(self):
         if self._needs_reset:
             raise RuntimeError("PtGVecEnv: call reset() before step()")
+        if self.norm_reward:
+            return self._step_wait_device()
+        eng = self.engine
+        slot = self._slot
+        self._slot = (slot + 1) % len(self._blk)
+        # ONE library call: actions in, kernel(s), outputs back, one synchronisation; raises on an invalid action (reference: IndexError)
+        rc = eng._L.ptg_step_host(eng._h, self._act_ptr, self._act_kind, self._blk_ptr[slot], self._final_ptr, self._info_ptr,
+                                  self._n_done_ref, self._stream_ptr)
+        if rc:
+            eng._chk(rc)
+        mat, rew, done = self._views[slot]
+        obs = self._obs_dict(mat, copy=self._copy_out)
+        rews = rew.astype(np.float32)                         # always a new array
+        dones = done.astype(bool)
+        self._old_reward = rews
+        infos = self._finish_infos(dones, self._n_done.value, self._final_mat)
+        if self.noise_mode == "numpy":
+            self._steps_since_refill += 1
+            if self._steps_since_refill >= self._tape_len:
+                self._refill_tape()
+        return obs, rews, dones, infos
+
+    def _step_wait_device(self):
+        """norm_reward=True: the step and the VecNormalize kernels run on device tensors, then one synchronisation for the copies."""
         eng = self.engine
         obs_t, rew_t, done_t = eng.step(self._actions)
-        # device -> pinned host staging on the step's stream, ONE synchronisation for the kernel and the copies; everything
-        # handed to the caller below is a fresh array (SB3 keeps the previous observation across the next step() call)
         raw_rew_t = rew_t
-        if self.norm_reward:                                  # same stream: moments, running statistics, clip(r / sqrt(var + eps))
-            rew_t = eng.vn_normalize(rew_t, done_t, training=self.training)
+        rew_t = eng.vn_normalize(rew_t, done_t, training=self.training)      # same stream: moments, running statistics, clip(r / sqrt(var + eps))
         h_obs, h_rew, h_done = self._to_host("obs", eng.rows(obs_t)), self._to_host("rew", rew_t), self._to_host("done", done_t)
-        h_raw = self._to_host("raw_rew", raw_rew_t) if self.norm_reward else None
+        h_raw = self._to_host("raw_rew", raw_rew_t)
         h_info = self._to_host("info", eng.info) if eng.info is not None else None
         eng.sync()                                            # raises on an invalid action (reference: IndexError)
         obs = h_obs.numpy()
         rews = h_rew.numpy().astype(np.float32)
         dones = h_done.numpy().astype(bool)
-        self._old_reward = h_raw.numpy().astype(np.float32) if h_raw is not None else rews
-        infos = [{} for _ in range(self.num_envs)]
+        self._old_reward = h_raw.numpy().astype(np.float32)
         if h_info is not None:
-            info = h_info.numpy()
-            for e in range(self.num_envs):
-                infos[e] = self._info_dict(info[e])
-        if dones.any():
+            self._info_host[...] = h_info.numpy()
+        final = None
+        n_done = int(dones.sum())
+        if n_done:
             h_final = self._to_host("final", eng.rows(eng.final_obs))      # rare: only steps on which an episode ends
             eng.sync()
             final = h_final.numpy()
-            r, l, ids = eng.finished_episodes()
-            now = time.time()
-            ep = {int(i): (float(rr), int(ll)) for rr, ll, i in zip(r, l, ids)}
-            for e in np.nonzero(dones)[0]:
-                infos[e]["terminal_observation"] = self._obs_row_dict(final[e])
-                infos[e]["TimeLimit.truncated"] = False
-                rr, ll = ep.get(int(e), (float("nan"), 0))
-                infos[e]["episode"] = {"r": round(rr, 6), "l": ll, "t": round(now - self._t0, 6)}
-                self._ep_start[e] = now
+            if not self.training:                             # VecNormalize: self.returns[dones] = 0 also with frozen statistics
+                _, ret = eng.vn_get()
+                ret[dones] = 0.0
+                eng.vn_set(returns=ret)
+        infos = self._finish_infos(dones, n_done, final)
         if self.noise_mode == "numpy":
             self._steps_since_refill += 1
             if self._steps_since_refill >= self._tape_len:
                 self._refill_tape()
-        return self._obs_dict(obs), rews, dones, infos
+        return self._obs_dict(obs), rews, dones, infos          # copies: the staging buffers are reused by the next step
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """HipEngine.state_dict() plus the host side of the noise streams (noise="numpy": the per-env PCG64 generator states, the
+        tape and the refill counter), so that a resumed env continues with the draws the reference env would see."""
+        sd = {"engine": self.engine.state_dict(), "seed": self._seed, "noise_mode": self.noise_mode,
+              "steps_since_refill": self._steps_since_refill, "needs_reset": self._needs_reset}
+        if self._gens is not None:
+            sd["generators"] = [g.bit_generator.state for g in self._gens]
+            sd["tape"] = self._tape.copy()
+        return sd
+
+    def load_state_dict(self, sd):
+        assert sd["noise_mode"] == self.noise_mode
+        if self._needs_reset:
+            self.reset()
+        self.engine.load_state_dict(sd["engine"])
+        self._seed = sd.get("seed")
+        if "generators" in sd:
+            for g, st in zip(self._gens, sd["generators"]):
+                g.bit_generator.state = st
+            self._tape = sd["tape"].copy()
+        self._steps_since_refill = int(sd["steps_since_refill"])
+        self._needs_reset = bool(sd["needs_reset"])
 
     def step_tensors(self, actions):
         """Device path: enqueue one step, return (obs, rewards, dones) ROCm tensors without synchronising."""
