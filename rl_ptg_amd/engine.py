@@ -318,7 +318,7 @@ class HipEngine:
             self.vn_set(stats=sd["vn"]["stats"], returns=sd["vn"]["returns"])
 
     def finished_episodes(self, cap=None):
-        cap = 2 * self.n if cap is None else int(cap)
+        cap = max(2 * self.n, 1024) if cap is None else int(cap)          # the library's ring holds max(2 n, 1024) entries
         r = np.zeros(cap)
         l = np.zeros(cap, np.int32)
         ids = np.zeros(cap, np.int32)

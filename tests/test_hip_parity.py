@@ -543,8 +543,8 @@ def test_hot_kernels_raw_features_and_launch_variants(layout, variant):
 def test_sb3_flat_layout_equals_flattened_dict_observation(raw_modified, out_dtype):
     """obs_layout="sb3_flat": rows are what SB3's CombinedExtractor feeds a MultiInputPolicy (sub-spaces in sorted key order,
     Discrete(6) METH_STATUS one-hot).  stable-baselines3 (2.x, un-vendored, not installed here) is restated in
-    rl_ptg_amd.vec_env.sb3_flat_features; the native layout must equal that function applied to the row-major output, bit for
-    bit -- hot kernels (step + fused rollout, ragged last wave), generic kernels (float64, terminating steps with reset rows and
+    oracle/sb3_flat_oracle.py (test infrastructure, pinned by hand-built known answers); the native layout must equal that
+    restatement applied to the row-major output, bit for bit, and so must the product's torch helper sb3_flat_features -- hot kernels (step + fused rollout, ragged last wave), generic kernels (float64, terminating steps with reset rows and
     terminal observations) alike."""
     import torch
     from rl_ptg_amd.engine import HipEngine
@@ -572,7 +572,15 @@ def test_sb3_flat_layout_equals_flattened_dict_observation(raw_modified, out_dty
         eng.close()
     F = res["row"][0]
     assert res["sb3_flat"][0] == F + 5 == (40 if raw_modified == "mod" else 31)
-    flat = lambda x: sb3_flat_features(x, raw_modified=raw_modified)
+    import os, sys
+    sys.path.insert(0, os.path.join(H.ROOT, "oracle"))
+    import sb3_flat_oracle
+
+    def flat(x):                                          # the independent checker; float64 engines keep float64 rows (values are exact either way)
+        xs = x.cpu().numpy()
+        y = sb3_flat_oracle.flatten_rows(xs.reshape(-1, xs.shape[-1]).astype(np.float64), raw_modified).reshape(xs.shape[:-1] + (-1,))
+        assert np.array_equal(y, sb3_flat_features(x, raw_modified=raw_modified).cpu().numpy().astype(np.float32))     # product helper == oracle
+        return torch.from_numpy(y.astype(xs.dtype)).to(x.device) if xs.dtype == np.float32 else sb3_flat_features(x, raw_modified=raw_modified)
     assert torch.equal(res["sb3_flat"][1], flat(res["row"][1]))
     assert torch.equal(res["sb3_flat"][2], flat(res["row"][2]))
     assert torch.equal(res["sb3_flat"][5], flat(res["row"][5]))

@@ -82,3 +82,24 @@ def test_sticky_action_tape_holds_actions_between_switches():
     iid = sticky_actions_device(400, 64, seed=1, device=torch.device("cpu"), p_switch=1.0).numpy()
     assert abs((iid[1:] != iid[:-1]).mean() - 0.8) < 0.02
     assert sticky_actions_device(0, 5, seed=1, device=torch.device("cpu")).shape == (0, 5)
+
+
+def test_sb3_flat_oracle_known_answers():
+    """oracle/sb3_flat_oracle.py against hand-built rows: sub-spaces in sorted-key order, METH_STATUS as a one-hot of 6 (SB3
+    preprocess_obs + CombinedExtractor, restated; unpinned against SB3 itself)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import sb3_flat_oracle as fo
+    # 'mod', canonical order: Pot_Reward[13] Part_Full[13] METH_STATUS T_CAT H2_in CH4_syn H2_res H2O_DE Elec_Heating sin cos
+    row = np.concatenate([100 + np.arange(13), 200 + np.arange(13), [4], [0.31, 0.32, 0.33, 0.34, 0.35, 0.36, 0.37, 0.38]]).astype(np.float64)
+    flat = fo.flatten_rows(row[None, :], "mod")[0]
+    # sorted keys: CH4_syn, Elec_Heating, H2O_DE, H2_in, H2_res, METH_STATUS(6), Part_Full(13), Pot_Reward(13), T_CAT, cos, sin
+    want = np.concatenate([[0.33, 0.36, 0.35, 0.32, 0.34], [0, 0, 0, 0, 1, 0], 200 + np.arange(13), 100 + np.arange(13), [0.31, 0.38, 0.37]]).astype(np.float32)
+    assert flat.dtype == np.float32 and flat.shape == (40,) and np.array_equal(flat, want)
+    # 'raw': Elec_Price[13] Gas_Price[2] EUA_Price[2] METH_STATUS ...
+    row = np.concatenate([100 + np.arange(13), [21, 22], [31, 32], [0], [0.31, 0.32, 0.33, 0.34, 0.35, 0.36, 0.37, 0.38]]).astype(np.float64)
+    flat = fo.flatten_rows(row[None, :], "raw")[0]
+    # sorted: CH4_syn, EUA_Price(2), Elec_Heating, Elec_Price(13), Gas_Price(2), H2O_DE, H2_in, H2_res, METH_STATUS(6), T_CAT, cos, sin
+    want = np.concatenate([[0.33], [31, 32], [0.36], 100 + np.arange(13), [21, 22], [0.35, 0.32, 0.34], [1, 0, 0, 0, 0, 0], [0.31, 0.38, 0.37]]).astype(np.float32)
+    assert flat.shape == (31,) and np.array_equal(flat, want)
+    assert sorted(k for k, _ in fo.reference_keys("mod"))[5] == "METH_STATUS"
