@@ -305,7 +305,7 @@ def main():
                                  "frac": b_alg * n * STEADY_T / t / 1e9 / HBM_PEAK_GBPS, "env_steps_per_s_device": n * STEADY_T / t}
         return d, res
 
-    head, res = leg(args.path, args.obs_layout, args.out_dtype, steady=args.steady)
+    head, res = leg(args.path, args.obs_layout, args.out_dtype, steady=args.steady and n <= 131072)     # (400-step buffers: 3.7 GB per 65 536 envs)
     also = {}
     if args.also:
         other = "rollout" if args.path == "step" else "step"

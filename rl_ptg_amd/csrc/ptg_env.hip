@@ -1109,22 +1109,34 @@ struct RowTile {
     }
     __device__ __forceinline__ void put_u(int q, OUT v) const { put(q, v); }
     // rows = address of the wave's first row; all 64 lanes of the wave must be live
-    __device__ __forceinline__ void flush(OUT* rows) const
+    // PARTIAL = false: all 64 rows exist.  PARTIAL = true: only the first n_valid rows do (the batch's last, ragged wave): whole
+    // 16-byte pieces of that prefix, then its last few elements one by one -- the rows are one contiguous block either way, so
+    // a ragged wave needs no second, per-lane addressing scheme (that second path cost the masked kernels ~100 spilled registers)
+    template <bool PARTIAL = false>
+    __device__ __forceinline__ void flush(OUT* rows, int n_valid = 64) const
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const int n_el = n_valid * F, n16 = PARTIAL ? n_el / EPP : N4;
+        if (PITCH == F) {
 #pragma unroll
-        for (int j = 0; j < (N4 + 63) / 64; j++) {
-            const int g = lane + 64 * j;
-            if (g < N4) {
-                vf4 v;
-                if (PITCH == F) v = ((const vf4*)t)[g];
-                else {                                     // padded pitch: float32 flat rows only
-                    const float* src = (const float*)t + (g / (F / 4)) * PITCH + (g % (F / 4)) * 4;      // 4-byte aligned only
-                    v = vf4{src[0], src[1], src[2], src[3]};
-                }
-                __builtin_nontemporal_store(v, (vf4*)rows + g);
+            for (int j = 0; j < (N4 + 63) / 64; j++) {
+                const int g = lane + 64 * j;
+                if (g < N4 && (!PARTIAL || g < n16)) __builtin_nontemporal_store(((const vf4*)t)[g], (vf4*)rows + g);
             }
+        } else {                                            // padded pitch (float32 SB3_FLAT rows): four 4-byte LDS reads per piece; two pieces
+#pragma unroll 2                                            // in flight keep the kernel inside its register budget
+            for (int j = 0; j < (N4 + 63) / 64; j++) {
+                const int g = lane + 64 * j;
+                if (g < N4 && (!PARTIAL || g < n16)) {
+                    const float* src = (const float*)t + (g / (F / 4)) * PITCH + (g % (F / 4)) * 4;
+                    __builtin_nontemporal_store(vf4{src[0], src[1], src[2], src[3]}, (vf4*)rows + g);
+                }
+            }
+        }
+        if (PARTIAL && PITCH == F) {                        // (padded pitch: F is a multiple of 4, no tail)
+            const int q = n16 * EPP + lane;
+            if (lane < EPP && q < n_el) __builtin_nontemporal_store(t[q], rows + q);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1194,21 +1206,22 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
     HotLoads<OUT> Q;
     hot_front<MOD, NOISE, OUT>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
     const OUT r = hot_back<OUT>(P, R, Q, setc, e, live);
-    const bool wave_full = __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // e_raw of lane 0: the wave's first env
-    if (!FM && wave_full) {
-        OUT* rows = obs + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
+    const int e_wave = __builtin_amdgcn_readfirstlane(e_raw);                 // the wave's first env
+    if (!FM && e_wave < P.N) {                                                   // rows: through the wave's LDS tile, out as one block
+        OUT* rows = obs + (size_t)e_wave * P.F;
         const RowTile<MOD, FLAT, OUT> tile(s_tile, threadIdx.x >> 6);
         hot_store_obs<MOD>(P, tile, Q, R.flags & 7);
-        tile.flush(rows);
+        if (e_wave + 63 < P.N) tile.flush(rows);
+        else tile.template flush<true>(rows, P.N - e_wave);
     }
-    if (live) {
-        if (FM || !wave_full) hot_store_obs<MOD>(P, HotRow<FM, MOD, OUT>(obs, P, e), Q, R.flags & 7);
-        st_off<OUT>(rew, (unsigned)e * (unsigned)sizeof(OUT), r);
-        st_off<uint8_t>(done, (unsigned)e, 0);
-        StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
-        StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
-        P.st_a[e] = na; P.st_b[e] = nb;
-    }
+    // no `if (live)`: a lane past the batch shadows env N - 1 exactly (same state, same action, same noise stream), so what it
+    // stores is the value the real lane stores to the same address -- harmless, and it keeps the stores out of divergent code
+    if (FM) hot_store_obs<MOD>(P, HotRow<true, MOD, OUT>(obs, P, e), Q, R.flags & 7);
+    st_off<OUT>(rew, (unsigned)e * (unsigned)sizeof(OUT), r);
+    st_off<uint8_t>(done, (unsigned)e, 0);
+    StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
+    StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
+    P.st_a[e] = na; P.st_b[e] = nb;
 }
 
 // Producer / consumer form of the fused rollout ("split gather").  Half of every workgroup's waves (producers) run ONLY the
@@ -1340,7 +1353,8 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     // exact (a skipped-stores path makes it assume the worst and drain the queue every step)
     const bool live = FULL || e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
-    const bool wave_full = FULL || __builtin_amdgcn_readfirstlane(e_raw) + 63 < P.N;     // all 64 envs of this wave exist
+    const int e_wave = __builtin_amdgcn_readfirstlane(e_raw);                            // the wave's first env
+    const bool wave_full = FULL || e_wave + 63 < P.N;                                    // all 64 envs of this wave exist
     const StA a = P.st_a[e]; const StB b = P.st_b[e];
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
@@ -1526,18 +1540,19 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
             row.put_u(o + 7, sc.x);
             row.put_u(o + 8, sc.y);
         };
-        if (!FM && wave_full) {                             // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
-            OUT* rows = (OUT*)obs_t + (size_t)__builtin_amdgcn_readfirstlane(e_raw) * P.F;
+        if (!FM && (FULL || e_wave < P.N)) {                // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
+            OUT* rows = (OUT*)obs_t + (size_t)e_wave * P.F;
             const int cw = (int)(threadIdx.x >> 6) - (NP >> 6);
             const RowTile<MOD, FLAT, OUT> tile(s_tiles, cw);
             emit(tile);
-            tile.flush(rows);
+            if (wave_full) tile.flush(rows);
+            else tile.template flush<true>(rows, P.N - e_wave);
         }
-        if (live) {
-            if (FM || !wave_full) emit(HotRow<FM, MOD, OUT>((OUT*)obs_t, P, e));
-            st_off<OUT>(rew_t, (unsigned)e * B, (OUT)rw);
-            st_off<uint8_t>(done_t, (unsigned)e, 0);
-        }
+        // lanes past the batch shadow env N - 1 and store what its real lane stores, to the same addresses: no divergent region
+        // around the stores (the masked form made the backend drain the whole vmcnt queue every step: 3.9 vs 1.5 us per step)
+        if (FM) emit(HotRow<true, MOD, OUT>((OUT*)obs_t, P, e));
+        st_off<OUT>(rew_t, (unsigned)e * B, (OUT)rw);
+        st_off<uint8_t>(done_t, (unsigned)e, 0);
         obs_t += NF4; rew_t += (size_t)P.N * B; done_t += P.N;
         if (reload) {
             if (slide && MLDS) {                            // the new elements take the slots of the ones that left the windows
@@ -1600,15 +1615,13 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
             }
         }
     }
-    if (live) {
-        if (producer) {
-            R.flags = (R.flags & 0x1FFFFu) | (tk << 17);
-            StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
-            P.st_a[e] = na;
-            *(int2*)((char*)&P.st_b[e] + 8) = make_int2(R.act_d, R.nctr);
-        } else {
-            *(double*)&P.st_b[e] = R.cum;
-        }
+    if (producer) {                                         // (shadow lanes: the same values to env N - 1's slots)
+        R.flags = (R.flags & 0x1FFFFu) | (tk << 17);
+        StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
+        P.st_a[e] = na;
+        *(int2*)((char*)&P.st_b[e] + 8) = make_int2(R.act_d, R.nctr);
+    } else {
+        *(double*)&P.st_b[e] = R.cum;
     }
 }
 
@@ -2082,11 +2095,18 @@ PcPlan pc_plan(const ptg_env* h)
 {
     PcPlan pl;
     pl.chunk = std::max(256, h->knob_chunk / 256 * 256);
+    {   // a batch wider than one launch is cut into EQUAL slices (100 000 envs: 2 x ~50 000, not 65 536 + 34 464): every launch then
+        // runs at the same bandwidth-bound pace instead of a full one followed by a half-empty, latency-bound one
+        const int slices = (h->n + pl.chunk - 1) / pl.chunk;
+        pl.chunk = std::max(256, ((h->n + slices - 1) / slices + 255) / 256 * 256);
+    }
     pl.fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);     // + the row-major tiles, below
     pl.lut_bytes = 16 * (((size_t)N_DEST * h->Tvals.size() * 2 + 15) / 16);
     pl.lds_max = 160 * 1024 - 512;
-    pl.block = 128;                                         // half producers, half consumers; >= 256 workgroups when possible
-    while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block) >= 256) pl.block *= 2;     // block/2 envs per workgroup
+    // half producers, half consumers: the smallest workgroup (64, 128 or 256 envs) whose grid still fits the chip in ONE round of
+    // workgroups (one per CU: the LDS stage allows no second one) -- small batches spread over many CUs, large ones do not queue
+    pl.block = 128;
+    while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block / 2) > 256) pl.block *= 2;
     if (h->knob_block) pl.block = h->knob_block;
     const int np = pl.block / 2;
     if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F) * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);      // one [64][pitch] tile per consumer wave (RowTile::PITCH)
