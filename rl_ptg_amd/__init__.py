@@ -5,7 +5,7 @@
 __version__ = "0.1.0"
 
 _LAZY = {"PtGVecEnv": "vec_env", "PTGEnv": "vec_env", "HipEngine": "engine", "PtgError": "engine", "EnvConfig": "config",
-         "Preprocessing": "prep", "EnvSpec": "prep", "synthetic_spec": "prep", "load_op_tables": "tables"}
+         "Preprocessing": "prep", "EnvSpec": "prep", "synthetic_spec": "prep", "load_op_tables": "tables", "load_data": "market", "import_market_data": "market"}
 
 
 def __getattr__(name):
