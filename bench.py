@@ -119,8 +119,8 @@ def main():
     ap.add_argument("--scenario", type=int, default=1)
     ap.add_argument("--operation", default="OP1")
     ap.add_argument("--out-dtype", choices=["float32", "float64"], default="float32")
-    ap.add_argument("--obs-layout", choices=["row", "feature", "sb3_flat"], default="row",
-                    help="observation matrix layout: row-major [N][F] (the boundary's), feature-major [F][N], or SB3's flattened [N][F+5] rows")
+    ap.add_argument("--obs-layout", choices=["row", "feature", "sb3_flat", "split"], default="row",
+                    help="observation matrix layout: row-major [N][F] (the boundary's), feature-major [F][N], SB3's flattened [N][F+5] rows, or the 16-column env part + series indices (\"split\")")
     ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
     ap.add_argument("--noise", choices=["rng", "tape"], default="rng", help="in-kernel counter RNG or a device-filled tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTG_ABI_VERSION 3   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout */
+#define PTG_ABI_VERSION 3   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -57,8 +57,17 @@ enum { PTG_OUT_F32 = 0, PTG_OUT_F64 = 1 };                    /* element type of
  * SB3_FLAT [N][F + 5] is the row SB3's CombinedExtractor builds from the Dict observation (the reference's policies are
  * "MultiInputPolicy"): sub-spaces concatenated in sorted key order, the Discrete(6) METH_STATUS one-hot encoded -- 40
  * columns for 'mod', 31 for 'raw' at price_ahead 13; ptg_obs_dim() reports the width.  Replaces: obs_as_tensor +
- * preprocess_obs + CombinedExtractor.forward on the caller's side. */
-enum { PTG_OBS_ROW_MAJOR = 0, PTG_OBS_FEATURE_MAJOR = 1, PTG_OBS_SB3_FLAT = 2 };
+ * preprocess_obs + CombinedExtractor.forward on the caller's side.
+ * SPLIT [N][16] (float32): the part of the SB3_FLAT row that depends on the env's own state, plus WHERE its market features are:
+ *   columns 0-5 METH_STATUS one-hot, 6 T_CAT, 7 H2_in, 8 CH4_syn, 9 H2_res, 10 H2O_DE, 11 Elec_Heating, 12 sin, 13 cos,
+ *   14 hour index, 15 day index -- the start of the env's 13-hour (2-day) windows in the normalised feature series of
+ *   ptg_market_feature_series (index = market_set * series_length + hour or day; exact in float32 up to 2^24).
+ * The 26 ('raw': 17) market features of a row are a function of that index alone, so a policy's first layer can be evaluated as
+ *   W_env . row[0:14] + G[hour index] (+ G_day[day index]),  G = the market columns of W applied to every window of the series
+ * (rl_ptg_amd/policy_split.py): 73 instead of 169 bytes per env-step leave the env kernel, and the first layer multiplies 14
+ * instead of 40 inputs.  Replaces: the market sub-spaces of the Dict observation going through CombinedExtractor into the first
+ * Linear of the reference's MultiInputPolicy (src/rl_config_agent.py:126-149). */
+enum { PTG_OBS_ROW_MAJOR = 0, PTG_OBS_FEATURE_MAJOR = 1, PTG_OBS_SB3_FLAT = 2, PTG_OBS_SPLIT = 3 };
 
 /* Constants of the env: the flat kwargs of Preprocessing.dict_env_kwargs (src/rl_utils.py:345-365), same names.
  * Replaces: the attribute set PTGEnv.__init__ copies from dict_input (env/ptg_gym_env.py:40). */
@@ -234,6 +243,11 @@ int ptg_vn_apply(ptg_env* env, const void* rew_dev, int n_steps, const double* m
 /* running statistics {mean, var, count} and the per-env discounted returns (either pointer may be NULL) */
 int ptg_vn_get(ptg_env* env, double* stats3_host, double* returns_host);
 int ptg_vn_set(ptg_env* env, const double* stats3_host, const double* returns_host);
+
+/* The pre-normalised float32 market feature series the kernels read, as [n_sets][series length]: which = 0 Pot_Reward ('raw':
+ * Elec_Price) hourly, 1 Part_Full hourly ('mod' only), 2 Gas_Price daily, 3 EUA_Price daily.  out_host NULL: only *count.
+ * For the SPLIT layout's consumer (column 14 / 15 of a row index these arrays). */
+int ptg_market_feature_series(ptg_env* env, int which, float* out_host, int cap, int* count);
 
 /* diagnostics for tests: the device-built lookup products */
 int ptg_debug_get_index_lut(ptg_env* env, double* T_values_host, int32_t* lut_host /*[6][nT]*/, int* n_T);

@@ -14,7 +14,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 N_TABLES, N_INFO = 17, 24
 ACT_I32, ACT_F32, ACT_I64 = 0, 1, 2
 OUT_F32, OUT_F64 = 0, 1
-OBS_ROW_MAJOR, OBS_FEATURE_MAJOR, OBS_SB3_FLAT = 0, 1, 2
+OBS_ROW_MAJOR, OBS_FEATURE_MAJOR, OBS_SB3_FLAT, OBS_SPLIT = 0, 1, 2, 3
 
 _D1 = ["noise"]
 _I1 = ["eps_len_d", "sim_step", "time_step_op", "price_ahead"]
@@ -60,7 +60,7 @@ EXPORTS = ["ptg_abi_version", "ptg_create", "ptg_destroy", "ptg_num_envs", "ptg_
            "ptg_set_market_assignment", "ptg_set_episode_plan", "ptg_set_noise_tape", "ptg_set_noise_rng", "ptg_set_global_env_offset", "ptg_fill_noise_tape",
            "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_profile", "ptg_profile_read", "ptg_sync", "ptg_get_state", "ptg_set_state",
            "ptg_finished_episodes", "ptg_vn_init", "ptg_vn_batch_moments", "ptg_vn_apply", "ptg_vn_get", "ptg_vn_set",
-           "ptg_debug_get_index_lut", "ptg_debug_window_record"]
+           "ptg_market_feature_series", "ptg_debug_get_index_lut", "ptg_debug_window_record"]
 
 
 def build(force=False, verbose=False):
@@ -123,6 +123,7 @@ def lib():
     L.ptg_vn_apply.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ptg_vn_get.argtypes = [vp, dp, dp]
     L.ptg_vn_set.argtypes = [vp, dp, dp]
+    L.ptg_market_feature_series.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.ptg_debug_get_index_lut.argtypes = [vp, dp, i32p, C.POINTER(C.c_int)]
     L.ptg_debug_window_record.argtypes = [vp, C.c_int, C.c_int, dp]
     for name in EXPORTS:

@@ -106,6 +106,7 @@ struct DevParams {
     // finished-episode list
     double* fin_ret; int* fin_len; int* fin_env; int* fin_count; int fin_cap;
     const int* cmap; int q_stat;          // SB3_FLAT layout: canonical column -> flat column; canonical index of METH_STATUS (else cmap = null)
+    int split;                            // SPLIT layout (16 columns: status one-hot, 8 env features, hour / day series index; q_stat set too)
     int* err;                             // [2] in pinned HOST memory: {invalid action seen, price index out of range}; kernels store 1 (plain
                                           // stores of a constant need no atomic), the host reads it after a stream synchronise -- no copy
 };
@@ -378,14 +379,21 @@ __device__ __forceinline__ int step_ints(const DevParams& P, const int2* tabmeta
 // lanes of a wave are consecutive envs, so every feature store is one contiguous 256-B (f32) / 512-B (f64) segment.
 template <typename OUT, bool FM>
 struct ObsRow {
-    OUT* p; size_t stride; const int* cmap; int q_stat;
+    OUT* p; size_t stride; const int* cmap; int q_stat; bool split;
     __device__ __forceinline__ ObsRow(OUT* base, const DevParams& P, int e)
-        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.N : 1), cmap(FM ? nullptr : P.cmap), q_stat(P.q_stat) {}
+        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.N : 1), cmap(FM ? nullptr : P.cmap), q_stat(P.q_stat),
+          split(!FM && P.split) {}
     // q = canonical column (the reference's observation order); SB3_FLAT rows hold the columns in sorted-key order with
     // METH_STATUS one-hot over 6 classes
     __device__ __forceinline__ void put(int q, OUT v) const
     {
-        if (!FM && cmap) {
+        if (!FM && split) {                     // the market columns are not stored: the consumer reads them through the series indices
+            if (q < q_stat) return;
+            if (q == q_stat) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) p[j] = (OUT)(((int)v == j) ? 1 : 0);
+            } else p[5 + (q - q_stat)] = v;     // canonical q_stat + 1 .. + 8 -> columns 6 .. 13
+        } else if (!FM && cmap) {
             const int c = cmap[q];
             if (q == q_stat) {
 #pragma unroll
@@ -393,6 +401,11 @@ struct ObsRow {
             } else p[c] = v;
         } else if (FM) __builtin_nontemporal_store(v, p + (size_t)q * stride);     // coalesced plane segments, never re-read: keep them out of L2
         else p[(size_t)q * stride] = v;
+    }
+    // SPLIT layout: where this env's 13-hour / 2-day windows start in the (market-set-major) feature series
+    __device__ __forceinline__ void put_idx(unsigned hour_idx, unsigned day_idx) const
+    {
+        if (!FM && split) { p[14] = (OUT)hour_idx; p[15] = (OUT)day_idx; }
     }
     __device__ __forceinline__ void copy_row_from(const ObsRow& src, int F) const     // same layout on both sides
     {
@@ -477,6 +490,7 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Regs& R, int e, co
         PriceFeatures<OUT, FAST, FM, PAC> pf;
         pf.load(P, mset, R.b.act_d * 24, R.b.act_d);
         pf.store(P, row);
+        row.put_idx(mset * (unsigned)P.hstride + (unsigned)(R.b.act_d * 24), mset * (unsigned)P.dstride + (unsigned)R.b.act_d);
         const int o = P.mod ? 2 * P.PA : P.PA + 4;
         row.put(o + 0, (OUT)1.0);
         row.put(o + 1, (OUT)((P.T_init - P.T_lo) / P.T_rng));
@@ -566,6 +580,7 @@ __device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta
         if (row) {
             const float2 sc = P.sincos32[kk];
             pf.store(P, row);
+            row.put_idx(mset * (unsigned)P.hstride + (unsigned)H, mset * (unsigned)P.dstride + (unsigned)D);
             row.put(o + 0, (OUT)s);
             for (int q = 0; q < 6; q++) row.put(o + 1 + q, (OUT)rec.feat[q]);
             row.put(o + 7, (OUT)sc.x);
@@ -586,6 +601,7 @@ __device__ __forceinline__ bool env_step(const DevParams& P, const int2* tabmeta
         // :206-217 + :219-249 observation row
         if (row) {
             pf.store(P, row);
+            row.put_idx(mset * (unsigned)P.hstride + (unsigned)H, mset * (unsigned)P.dstride + (unsigned)D);
             row.put(o + 0, (OUT)s);
             row.put(o + 1, (OUT)((rec.T - P.T_lo) / P.T_rng));
             row.put(o + 2, (OUT)((H2 - P.h2_lo) / P.h2_rng));
@@ -619,11 +635,11 @@ __device__ __forceinline__ void push_finished(const DevParams& P, bool done, int
     if (m == 0) return;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(P.fin_count, __popcll(m));
+    unsigned base = 0;                                      // the running count is unsigned: it may wrap after 2^32 episodes, a slot never goes negative
+    if (lane == leader) base = atomicAdd((unsigned*)P.fin_count, (unsigned)__popcll(m));
     base = __shfl(base, leader);
     if (done) {
-        const int slot = (base + __popcll(m & ((1ull << lane) - 1ull))) % P.fin_cap;
+        const unsigned slot = (base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % (unsigned)P.fin_cap;
         P.fin_ret[slot] = ret; P.fin_len[slot] = len; P.fin_env[slot] = e;
     }
 }
@@ -1041,6 +1057,7 @@ struct HotRow {                  // observation row addressing: uniform base + 3
     __device__ __forceinline__ void put(int q, OUT v) const;
     // same address as (uniform pointer advanced by SALU) + (the one lane offset): no per-feature offset registers
     __device__ __forceinline__ void put_u(int q, OUT v) const;
+    __device__ __forceinline__ void put_idx(unsigned, unsigned) const {}
 };
 
 // SB3_FLAT layout (price_ahead = 13): canonical column q -> column of the flat row, sub-spaces in sorted key order
@@ -1080,11 +1097,11 @@ __device__ __forceinline__ void HotRow<FM, MOD, OUT>::put_u(int q, OUT v) const
 // stores would be 64 scattered 4-byte writes each.  Instead every wave transposes its 64 rows through a private LDS tile and
 // writes them back as ONE contiguous block of 64 * F floats with dwordx4 stores (64 * 140 B = 70 full 128-byte lines).
 typedef float vf4 __attribute__((ext_vector_type(4)));
-template <bool MOD, bool FLAT, typename OUT = float>
+template <bool MOD, bool FLAT, typename OUT = float, bool SPLIT = false>
 struct RowTile {
     static constexpr int FC = MOD ? 35 : 26;               // canonical row width
     static constexpr int FMAX = FC + 5;                    // SB3_FLAT: METH_STATUS one-hot (6 columns for 1)
-    static constexpr int F = FLAT ? FMAX : FC;
+    static constexpr int F = SPLIT ? 16 : FLAT ? FMAX : FC;   // SPLIT: one-hot status (6), 8 env features, hour / day series index
     static constexpr int QS = MOD ? 26 : 17;               // canonical column of METH_STATUS
     static constexpr int EPP = 16 / (int)sizeof(OUT);      // elements per 16-byte piece (4 floats / 2 doubles)
     static constexpr int N4 = 64 * F / EPP;                // 16-byte pieces per wave block (float: 560 / 416, flat 640 / 496; double: 1120 / 832)
@@ -1092,7 +1109,7 @@ struct RowTile {
     // writes: measured 2.15 us per step); 41 is conflict-free, and because 40 is a multiple of 4 a float4 of the output
     // image never straddles two tile rows
     // (float64 rows: pitch 35 doubles = 70 dwords -- lanes l, l + 1 start 6 banks apart, an 8-byte store per lane is conflict-free)
-    static constexpr int PITCH = (F == 40) ? 41 : F;
+    static constexpr int PITCH = (F == 40) ? 41 : (F == 16) ? 17 : F;
     static constexpr int TILE = 64 * PITCH;                // elements per wave
     OUT* t;                                                // this wave's [64][PITCH] tile
     int lane;
@@ -1100,7 +1117,13 @@ struct RowTile {
     __device__ __forceinline__ void put(int q, OUT v) const
     {
         OUT* r = t + lane * PITCH;
-        if (FLAT) {
+        if (SPLIT) {
+            if (q < QS) return;
+            if (q == QS) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) r[j] = ((int)v == j) ? (OUT)1 : (OUT)0;
+            } else r[5 + (q - QS)] = v;
+        } else if (FLAT) {
             if (q == QS) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) r[flat_col<MOD>(QS) + j] = ((int)v == j) ? (OUT)1 : (OUT)0;
@@ -1108,6 +1131,10 @@ struct RowTile {
         } else r[q] = v;
     }
     __device__ __forceinline__ void put_u(int q, OUT v) const { put(q, v); }
+    __device__ __forceinline__ void put_idx(unsigned hour_idx, unsigned day_idx) const
+    {
+        if (SPLIT) { OUT* r = t + lane * PITCH; r[14] = (OUT)hour_idx; r[15] = (OUT)day_idx; }
+    }
     // rows = address of the wave's first row; all 64 lanes of the wave must be live
     // PARTIAL = false: all 64 rows exist.  PARTIAL = true: only the first n_valid rows do (the batch's last, ragged wave): whole
     // 16-byte pieces of that prefix, then its last few elements one by one -- the rows are one contiguous block either way, so
@@ -1154,6 +1181,7 @@ __device__ __forceinline__ void hot_store_obs(const HotParams& P, const Sink& ro
     put_rec_feats<false>(P, row, o, Q.rec);
     row.put(o + 7, Q.sc.x);
     row.put(o + 8, Q.sc.y);
+    row.put_idx(Q.hb4 >> 2, Q.db4 >> 2);
 }
 
 __device__ __forceinline__ void hot_stage_lds(const HotParams& P, HotLds& L)
@@ -1188,9 +1216,9 @@ __global__ void __launch_bounds__(256)
 k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0, OUT* __restrict__ obs, OUT* __restrict__ rew,
            uint8_t* __restrict__ done)
 {
-    constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
+    constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT, SPLIT = LAY == PTG_OBS_SPLIT;
     __shared__ HotLds L;
-    __shared__ __attribute__((aligned(16))) OUT s_tile[FM ? 4 : 4 * RowTile<MOD, FLAT, OUT>::TILE];   // row-major / flat: one tile per wave
+    __shared__ __attribute__((aligned(16))) OUT s_tile[FM ? 4 : 4 * RowTile<MOD, FLAT, OUT, SPLIT>::TILE];   // row-major / flat / split: one tile per wave
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
@@ -1209,7 +1237,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
     const int e_wave = __builtin_amdgcn_readfirstlane(e_raw);                 // the wave's first env
     if (!FM && e_wave < P.N) {                                                   // rows: through the wave's LDS tile, out as one block
         OUT* rows = obs + (size_t)e_wave * P.F;
-        const RowTile<MOD, FLAT, OUT> tile(s_tile, threadIdx.x >> 6);
+        const RowTile<MOD, FLAT, OUT, SPLIT> tile(s_tile, threadIdx.x >> 6);
         hot_store_obs<MOD>(P, tile, Q, R.flags & 7);
         if (e_wave + 63 < P.N) tile.flush(rows);
         else tile.template flush<true>(rows, P.N - e_wave);
@@ -1330,7 +1358,7 @@ __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows)
 {
-    constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT;
+    constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT, SPLIT = LAY == PTG_OBS_SPLIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256): NP producer lanes, NP consumer lanes
     const int nwork = blockDim.x;
@@ -1343,7 +1371,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     // are 52 of the 256 a lane may have, and the kernel spilled.  The two 13-hour windows are rings: slot of element q = (q + head) mod 13
     constexpr bool MLDS = sizeof(OUT) == 8;
     constexpr int NFM = MOD ? 26 : 17;
-    OUT* s_mkt = (OUT*)((unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * RowTile<MOD, FLAT, OUT>::TILE * B));
+    OUT* s_mkt = (OUT*)((unsigned char*)s_tiles + (FM ? 0 : (size_t)(NP >> 6) * RowTile<MOD, FLAT, OUT, SPLIT>::TILE * B));
     unsigned char* s_act = (unsigned char*)s_mkt + (MLDS ? (size_t)NFM * NP * B : 0);      // [T][NP] decoded actions
     unsigned short* s_lut = (unsigned short*)(s_act + 16 * (((size_t)T * NP + 15) / 16));
     const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NP;     // wave-uniform: NP is a multiple of 64
@@ -1468,6 +1496,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     PcNext<MOD, OUT> Mn;                                    // ... and what the next hour adds to it
     double2 setc = make_double2(0.0, 0.0);
     int hour_cur = 0, head = 0;                             // head: first slot of the feature rings (uniform: the hour is)
+    unsigned hb_cur = 0, db_cur = 0;                        // SPLIT layout: series indices of the current hour / day
     auto mkt_to_lds = [&]() {                               // the window just loaded into M -> LDS, rings at head 0
         if (MLDS) {
 #pragma unroll
@@ -1493,6 +1522,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         hour_cur = ((k0 + 1) * P.sim_step) / 3600;
         pc_load_market<MOD, OUT>(P, hb4, db4, M);
         mkt_to_lds();
+        hb_cur = hb4 >> 2; db_cur = db4 >> 2;
     }
     const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * B;
     char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of the step being finished
@@ -1539,11 +1569,12 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
             put_rec_feats<true>(P, row, o, rec);
             row.put_u(o + 7, sc.x);
             row.put_u(o + 8, sc.y);
+            row.put_idx(hb_cur, db_cur);
         };
         if (!FM && (FULL || e_wave < P.N)) {                // row-major: transpose the wave's 64 rows through LDS, one contiguous block out
             OUT* rows = (OUT*)obs_t + (size_t)e_wave * P.F;
             const int cw = (int)(threadIdx.x >> 6) - (NP >> 6);
-            const RowTile<MOD, FLAT, OUT> tile(s_tiles, cw);
+            const RowTile<MOD, FLAT, OUT, SPLIT> tile(s_tiles, cw);
             emit(tile);
             if (wave_full) tile.flush(rows);
             else tile.template flush<true>(rows, P.N - e_wave);
@@ -1579,6 +1610,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
                 M.el = Mn.el; M.gas = Mn.gas; M.eua = Mn.eua;
             } else { pc_load_market<MOD, OUT>(P, hb4n, db4n, M); mkt_to_lds(); }      // steps longer than an hour: a plain (waited-for) reload
             hour_cur = hour_next;
+            hb_cur = hb4n >> 2; db_cur = db4n >> 2;
         }
     };
     // iteration `it`: producers run step it (while it < T); consumers request step it-1 and finish step it-2.  The two roles
@@ -1776,7 +1808,7 @@ struct ptg_env {
     std::vector<double> Tvals;
     std::vector<int> tab_rows, rec_base;
     size_t rec_total = 0;
-    bool fast = false, fm = false, flat = false;
+    bool fast = false, fm = false, flat = false, split = false;
     double* d_tape = nullptr;
     unsigned short* d_lut16 = nullptr;
     unsigned short* d_rkey = nullptr;   // temperature keys of all window records (k_rollout_pc producers)
@@ -2067,7 +2099,7 @@ bool hot_eligible(const ptg_env* h)
 {
     // (SB3's flattened rows are float32 by construction: float64 SB3_FLAT rows stay with the generic kernels)
     const unsigned long long osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
-    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && !(h->flat && osz == 8) &&
+    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && !((h->flat || h->split) && osz == 8) &&
            (unsigned long long)h->n * h->F * osz < 0xFFFFFFFFull;
 }
 
@@ -2109,7 +2141,7 @@ PcPlan pc_plan(const ptg_env* h)
     while (pl.block < 512 && (long long)grid_for(std::min(pl.chunk, h->n), pl.block / 2) > 256) pl.block *= 2;
     if (h->knob_block) pl.block = h->knob_block;
     const int np = pl.block / 2;
-    if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F) * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);      // one [64][pitch] tile per consumer wave (RowTile::PITCH)
+    if (!h->fm) pl.fixed += (size_t)np * (h->F == 40 ? 41 : h->F == 16 ? 17 : h->F) * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);      // one [64][pitch] tile per consumer wave (RowTile::PITCH)
     if (h->cfg.out_dtype == PTG_OUT_F64) pl.fixed += (size_t)(h->P.mod ? 26 : 17) * np * 8;      // the market features' LDS home (k_rollout_pc, MLDS)
     // the _get_index lookup goes to LDS when that still leaves room for >= 64 staged steps
     pl.lds_lut = h->d_lut16 && pl.fixed + pl.lut_bytes + (size_t)64 * np + 64 <= pl.lds_max && !h->knob_no_lds_lut;
@@ -2201,6 +2233,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
             else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_);               \
         } else if ((H_)->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);  \
         else if ((H_)->flat) PTG_HOT_DISPATCH3(FN, PTG_OBS_SB3_FLAT, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);       \
+        else if ((H_)->split) PTG_HOT_DISPATCH3(FN, PTG_OBS_SPLIT, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);         \
         else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);                      \
     } while (0)
 #define PTG_NOARG
@@ -2263,7 +2296,7 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     if (cfg->time_step_op <= 0 || cfg->sim_step <= 0 || cfg->price_ahead < 1 || cfg->price_ahead > 64)
         return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad sim_step / time_step_op / price_ahead");
     if (cfg->out_dtype != PTG_OUT_F32 && cfg->out_dtype != PTG_OUT_F64) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad out_dtype");
-    if (cfg->obs_layout < PTG_OBS_ROW_MAJOR || cfg->obs_layout > PTG_OBS_SB3_FLAT) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad obs_layout");
+    if (cfg->obs_layout < PTG_OBS_ROW_MAJOR || cfg->obs_layout > PTG_OBS_SPLIT) return set_err(nullptr, PTG_E_INVALID, "ptg_create: bad obs_layout");
     if (cfg->eps_sim_steps < 7) return set_err(nullptr, PTG_E_INVALID, "ptg_create: eps_sim_steps must be >= 7");
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -2321,6 +2354,10 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         if ((rc = dev_upload(h, &d_cmap, cmap.data(), cmap.size()))) return fail(rc);
         P.cmap = d_cmap; P.q_stat = o;
         h->F += 5; h->flat = true;
+    }
+    if (cfg->obs_layout == PTG_OBS_SPLIT) {               // env part of the flat row + series indices (include/ptg_env.h)
+        P.split = 1; P.q_stat = cfg->raw_modified ? 2 * cfg->price_ahead : cfg->price_ahead + 4;
+        h->F = 16; h->split = true;
     }
     P.N = n_envs; P.S = h->S; P.sim_step = cfg->sim_step; P.eps_sim_steps = cfg->eps_sim_steps; P.PA = cfg->price_ahead;
     P.F = h->F; P.mod = cfg->raw_modified; P.eps_len_d = cfg->eps_len_d; P.E = 0; P.ep_stride = 0; P.tape_len = 0;
@@ -3015,13 +3052,13 @@ int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_hos
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     h->fin_maybe = false;
-    int total = 0;
-    HIP_TRY(h, hipMemcpy(&total, h->P.fin_count, sizeof(int), hipMemcpyDeviceToHost));
-    const int have = std::min(total, h->P.fin_cap);
+    unsigned total = 0;
+    HIP_TRY(h, hipMemcpy(&total, h->P.fin_count, sizeof(unsigned), hipMemcpyDeviceToHost));
+    const int have = (int)std::min<unsigned>(total, (unsigned)h->P.fin_cap);
     const int n = std::min(have, cap);
     // entries [total - have, total) are live (ring); hand out the oldest n of them: at most two contiguous pieces
     if (n > 0) {
-        const int cap_r = h->P.fin_cap, s0 = (total - have) % cap_r;
+        const int cap_r = h->P.fin_cap, s0 = (int)((total - (unsigned)have) % (unsigned)cap_r);
         const int n0 = std::min(n, cap_r - s0), n1 = n - n0;
         if (returns_host) {
             HIP_TRY(h, hipMemcpy(returns_host, h->P.fin_ret + s0, sizeof(double) * n0, hipMemcpyDeviceToHost));
@@ -3038,6 +3075,21 @@ int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_hos
     }
     HIP_TRY(h, hipMemset(h->P.fin_count, 0, sizeof(int)));
     *count = n;
+    return 0;
+}
+
+int ptg_market_feature_series(ptg_env* h, int which, float* out_host, int cap, int* count)
+{
+    if (!h || !count || which < 0 || which > 3 || cap < 0) return set_err(h, PTG_E_INVALID, "ptg_market_feature_series: bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool hourly = which < 2;
+    const int n = h->n_sets * (hourly ? h->P.n_hours : h->P.n_days);
+    const unsigned off = which == 0 ? 0u : which == 1 ? h->off_featB : which == 2 ? h->off_gasn : h->off_euan;
+    *count = n;
+    if (out_host) {
+        if (cap < n) return set_err(h, PTG_E_INVALID, "ptg_market_feature_series: buffer too small (%d < %d)", cap, n);
+        HIP_TRY(h, hipMemcpy(out_host, h->d_pool32 + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

@@ -47,7 +47,8 @@ class HipEngine:
         c = dict(consts)
         c.setdefault("t_cat_initial", 16.0)
         c["out_dtype"] = _lib.OUT_F64 if out_dtype == "float64" else _lib.OUT_F32
-        c["obs_layout"] = {"row": _lib.OBS_ROW_MAJOR, "feature": _lib.OBS_FEATURE_MAJOR, "sb3_flat": _lib.OBS_SB3_FLAT}[obs_layout]
+        c["obs_layout"] = {"row": _lib.OBS_ROW_MAJOR, "feature": _lib.OBS_FEATURE_MAJOR, "sb3_flat": _lib.OBS_SB3_FLAT,
+                           "split": _lib.OBS_SPLIT}[obs_layout]
         self.feature_major = obs_layout == "feature"
         for k in _lib.CONFIG_KEYS:
             setattr(cfg, k, c[k])
@@ -366,6 +367,18 @@ class HipEngine:
         st = None if stats is None else np.array([stats["mean"], stats["var"], stats["count"]], dtype=np.float64)
         rt = None if returns is None else np.ascontiguousarray(returns, dtype=np.float64)
         self._chk(self._L.ptg_vn_set(self._h, None if st is None else _dp(st), None if rt is None else _dp(rt)))
+
+    def market_feature_series(self):
+        """The pre-normalised float32 feature series the kernels read, each [n_sets, length]: dict(featA, featB (hourly), gas_n, eua_n
+        (daily)).  Columns 14 / 15 of a "split" observation row index the flattened arrays."""
+        out = {}
+        for which, name in enumerate(("featA", "featB", "gas_n", "eua_n")):
+            cnt = C.c_int(0)
+            self._chk(self._L.ptg_market_feature_series(self._h, which, None, 0, C.byref(cnt)))
+            a = np.zeros(cnt.value, np.float32)
+            self._chk(self._L.ptg_market_feature_series(self._h, which, a.ctypes.data_as(C.POINTER(C.c_float)), cnt.value, C.byref(cnt)))
+            out[name] = a.reshape(self.n_sets, -1)
+        return out
 
     def debug_get_index_lut(self):
         nT = C.c_int(0)

@@ -103,3 +103,26 @@ def test_sb3_flat_oracle_known_answers():
     want = np.concatenate([[0.33], [31, 32], [0.36], 100 + np.arange(13), [21, 22], [0.35, 0.32, 0.34], [1, 0, 0, 0, 0, 0], [0.31, 0.38, 0.37]]).astype(np.float32)
     assert flat.shape == (31,) and np.array_equal(flat, want)
     assert sorted(k for k, _ in fo.reference_keys("mod"))[5] == "METH_STATUS"
+
+
+def test_split_layout_columns_agree_with_the_flat_oracle():
+    """rl_ptg_amd.policy_split's column tables against oracle/sb3_flat_oracle.py: the 14 env columns of a split row land where the
+    flattened observation has them, and the market windows where the oracle puts Pot_Reward / Part_Full (Elec / Gas / EUA)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import sb3_flat_oracle as fo
+    from rl_ptg_amd.policy_split import FLAT_MOD, FLAT_RAW, SPLIT_ENV, env_columns, flat_rows_from_split
+    for rm, table in (("mod", FLAT_MOD), ("raw", FLAT_RAW)):
+        keys = dict(fo.reference_keys(rm))
+        off, c = {}, 0
+        for k in sorted(keys):
+            off[k] = c
+            c += 6 if k == "METH_STATUS" else keys[k]
+        assert off == table
+        assert env_columns(rm) == [off["METH_STATUS"] + j for j in range(6)] + [off[k] for k in SPLIT_ENV]
+    # a hand-built split row + series -> the flat row the oracle builds from the canonical row
+    fa, fb = np.arange(100, 160, dtype=np.float32), np.arange(200, 260, dtype=np.float32)
+    canon = np.concatenate([fa[7:20], fb[7:20], [3], [0.31, 0.32, 0.33, 0.34, 0.35, 0.36, 0.37, 0.38]]).astype(np.float64)
+    split = np.array([[0, 0, 0, 1, 0, 0, 0.31, 0.32, 0.33, 0.34, 0.35, 0.36, 0.37, 0.38, 7, 0]], dtype=np.float32)
+    got = flat_rows_from_split(split, {"featA": fa[None], "featB": fb[None], "gas_n": np.zeros((1, 4), np.float32), "eua_n": np.zeros((1, 4), np.float32)}, "mod")
+    assert np.array_equal(got, fo.flatten_rows(canon[None], "mod"))
