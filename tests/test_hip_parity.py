@@ -502,7 +502,7 @@ def test_fused_rollout_flags_invalid_discrete_action():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["row", "feature"])
-@pytest.mark.parametrize("variant", ["default", "no_lds_lut", "block128"])
+@pytest.mark.parametrize("variant", ["default", "no_lds_lut", "block128", "no_refresh", "refresh_always"])
 def test_hot_kernels_raw_features_and_launch_variants(layout, variant):
     """'raw' observations (26 columns: the row-major tile has an even stride) and the launch variants of the fused rollout
     (lookup table left in global memory, 64-env workgroups) against the generic kernels, bit for bit."""
@@ -512,7 +512,8 @@ def test_hot_kernels_raw_features_and_launch_variants(layout, variant):
     spec, _ = synthetic_spec(scenario=3, operation="OP2", eps_len_d=8, raw_modified="raw", train_steps=400000)
     n, K = 640, 120
     acts = np.random.default_rng(17).integers(0, 5, (K, n)).astype(np.int32)
-    env = {"default": {}, "no_lds_lut": {"PTG_NO_LDS_LUT": "1"}, "block128": {"PTG_BLOCK": "128"}}[variant]
+    env = {"default": {}, "no_lds_lut": {"PTG_NO_LDS_LUT": "1"}, "block128": {"PTG_BLOCK": "128"}, "no_refresh": {"PTG_NO_REFRESH": "1"},
+           "refresh_always": {"PTG_REFRESH_ALWAYS": "1"}}[variant]
     out = {}
     for route in ("generic", "hot"):
         e2 = dict(env) if route == "hot" else {"PTG_NO_HOT_KERNELS": "1"}
