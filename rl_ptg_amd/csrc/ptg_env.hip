@@ -1946,6 +1946,10 @@ int build_tables(ptg_env* h, const ptg_tables* tb)
         rec_total += (size_t)tb->rows[t] + 1;
     }
     double* d_raw = nullptr; int* d_key = nullptr; double* d_T = nullptr;
+    struct Scratch {                                        // build-time device scratch, released on every return path
+        double*& a; int*& b;
+        ~Scratch() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+    } scratch{d_raw, d_key};
     HIP_TRY(h, hipMalloc((void**)&d_raw, raw.size() * sizeof(double)));
     HIP_TRY(h, hipMalloc((void**)&d_key, rowkey.size() * sizeof(int)));
     HIP_TRY(h, hipMemcpy(d_raw, raw.data(), raw.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1995,7 +1999,6 @@ int build_tables(ptg_env* h, const ptg_tables* tb)
             if ((rc = dev_upload(h, &h->d_lut16, l16.data(), l16.size()))) return rc;
         }
     }
-    (void)hipFree(d_raw); (void)hipFree(d_key);
     return 0;
 }
 
@@ -2274,13 +2277,14 @@ void ptg_destroy(ptg_env* env)
 {
     if (!env) return;
     (void)hipSetDevice(env->device);
+    (void)hipDeviceSynchronize();                           // nothing of this handle (incl. the refresher's stream) is in flight any more
+    if (env->ref_stream) (void)hipStreamDestroy(env->ref_stream);
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->d_tape) (void)hipFree(env->d_tape);
     if (env->d_eps_ind) (void)hipFree(env->d_eps_ind);
     if (env->vn_partials) (void)hipFree(env->vn_partials);
     if (env->vn_den) (void)hipFree(env->vn_den);
     if (env->vn_moments) (void)hipFree(env->vn_moments);
-    if (env->ref_stream) { (void)hipStreamSynchronize(env->ref_stream); (void)hipStreamDestroy(env->ref_stream); }
     if (env->err_host) (void)hipHostFree(env->err_host);
     for (void* q : {env->hs_act, env->hs_out, env->hs_final, (void*)env->hs_info}) if (q) (void)hipFree(q);
     for (auto* v : {&env->prof_used, &env->prof_free})

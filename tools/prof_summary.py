@@ -12,13 +12,13 @@ bench_args = sys.argv[2] if len(sys.argv) > 2 else "--gpus 1 --steps 20 --warmup
 K = int(re.search(r"--steps (\d+)", bench_args).group(1)) if "--steps" in bench_args else 2000
 os.makedirs("profiles", exist_ok=True)
 ours = ("k_step", "k_rollout", "k_reset", "k_build", "k_fill", "k_init", "k_zero", "k_extract", "k_refresh", "k_vn")
-LAY = {"0": "row", "1": "feature", "2": "sb3_flat"}
+LAY = {"0": "row", "1": "feature", "2": "sb3_flat", "3": "split"}
 
 
 def short(name):
-    m = re.search(r"(k_rollout_pc|k_step_hot)<(\d)", name)
+    m = re.search(r"(k_rollout_pc|k_step_hot)<(\d)[^>]*?(float|double)>", name)
     if m:
-        return f"{m.group(1)}<{LAY[m.group(2)]}>"
+        return f"{m.group(1)}<{LAY[m.group(2)]}>" if m.group(3) == "float" else f"{m.group(1)}<{LAY[m.group(2)]},f64>"
     for k in ("k_refresh", "k_extract_keys", "k_step", "k_reset", "k_build_records", "k_build_argmin", "k_build_fast", "k_fill_noise", "k_init_state", "k_zero_noise_count"):
         if k in name:
             return k
@@ -52,8 +52,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 
 lines = [f"# rocprofv3 summary, {tag}", "",
          f"Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py {bench_args} --no-cpu-baseline` (1x MI355X, N = 65536 envs, BS1/OP1, float32,",
-         "in-kernel RNG).  bench.py runs three legs, each on a fresh handle: the headline `ptg_rollout` with row-major observations, `ptg_step`",
-         "(K launches replayed as one hipGraph) and `ptg_rollout` with feature-major observations.  Dispatches of `k_rollout_pc<row>` in trace order:",
+         "in-kernel RNG).  bench.py runs four legs, each on a fresh handle: the headline `ptg_rollout` with row-major observations, `ptg_step`",
+         "(K launches replayed as one hipGraph), `ptg_rollout` with feature-major observations and with float64 row-major observations (`<row,f64>`).",
+         "Dispatches of `k_rollout_pc<row>` in trace order:",
          f"the W-step warm-up launch from reset, THE TIMED {K}-step LAUNCH (bench.py's `roofline.avg_launch_us`), then the two 400-step",
          "steady-state launches (`steady_state`); `k_rollout_pc<feature>`: warm-up, timed.  `k_refresh` is the table refresher that runs beside",
          "every rollout launch on its own stream (DESIGN.md section 5).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the",
@@ -79,22 +80,25 @@ for k in sorted(pmc):
     fs = [v for _, v in sorted(pmc[k].get("FETCH_SIZE", []))]
     ws = [v for _, v in sorted(pmc[k].get("WRITE_SIZE", []))]
     layout = k[k.index("<") + 1:-1]
+    dt = "float32"
+    if layout.endswith(",f64"):
+        layout, dt = layout[:-4], "float64"
     if k.startswith("k_rollout_pc") and len(fs) > 1 and len(ws) > 1:
         f, w_ = fs[1], ws[1]                                  # the timed launch (trace order: warm-up, timed, ...)
         tot = 2 * f * 1024 + w_ * 1024
         lines.append(f"| {k} | timed {K}-step launch | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / K:.0f} B per step = {tot / K / 65536:.1f} B per env-step |")
-        traffic[f"rollout_{layout}_float32"] = {"bytes_per_step": tot / K, "steps_in_measured_launch": K}
+        traffic[f"rollout_{layout}_{dt}"] = {"bytes_per_step": tot / K, "steps_in_measured_launch": K}
         if len(fs) > 3 and len(ws) > 3 and len(fs) == len(ws):      # the two 400-step steady-state rollouts (each one or more launches): the second one
             h2 = (len(fs) - 2) // 2
             f, w_ = sum(fs[2 + h2:]), sum(ws[2 + h2:])
             tot = 2 * f * 1024 + w_ * 1024
             lines.append(f"| {k} | second 400-step steady rollout ({h2} launch(es)) | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / 400:.0f} B per step = {tot / 400 / 65536:.1f} B per env-step |")
-            traffic[f"rollout_{layout}_float32_steady"] = {"bytes_per_step": tot / 400, "steps_in_measured_launch": 400}
+            traffic[f"rollout_{layout}_{dt}_steady"] = {"bytes_per_step": tot / 400, "steps_in_measured_launch": 400}
     elif k.startswith("k_step_hot") and fs and ws:
         f, w_ = sum(fs) / len(fs), sum(ws) / len(ws)
         tot = 2 * f * 1024 + w_ * 1024
         lines.append(f"| {k} | average of {len(fs)} launches | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / 65536:.1f} B per env-step |")
-        traffic[f"step_{layout}_float32"] = {"bytes_per_launch": tot}
+        traffic[f"step_{layout}_{dt}"] = {"bytes_per_launch": tot}
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 if len(traffic) > 1:                                          # what bench.py reports as roofline.traffic
