@@ -176,7 +176,8 @@ int ptg_rollout(ptg_env* env, const void* actions_dev, int action_kind, int n_st
                 uint8_t* done_dev, void* stream);
 /* ptg_rollout that also records the 24 _get_info fields of every step: info_dev [T][N][24] float64 (key order of
  * env/ptg_gym_env.py:251-278, Meth_Action as its index).  Replaces: the per-step info dicts Postprocessing.test_performance
- * collects into its stats array (src/rl_utils.py:528-565).  Runs the generic step kernel T times. */
+ * collects into its stats array (src/rl_utils.py:528-565).  float64 outputs: the fused rollout kernel writes the rows (it evaluates
+ * the reference-order reward terms anyway); float32 outputs: the generic step kernel, T launches. */
 int ptg_rollout_info(ptg_env* env, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
                      uint8_t* done_dev, double* info_dev, void* stream);
 /* One vector step with HOST buffers in and out -- the call behind VecEnv.step_wait.  Replaces DummyVecEnv.step_wait's loop

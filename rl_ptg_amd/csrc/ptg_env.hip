@@ -813,6 +813,7 @@ struct HotParams {
     double noise_sigma, k_chp, k_eua;
     const RecFast* recf;
     const Rec* rec;                                   // float64 outputs: raw window means, reward in the reference's operand order
+    const double *pot_raw, *pf_raw;                   // un-normalised Pot_Reward / Part_Full series (info rows of the float64 rollout)
     RewC rc;
     const double* tape;
     const float* pool32;
@@ -1260,7 +1261,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
 // hour -- reloaded when the hour changes, one step ahead of use), the clock features (scalar loads: the step count is
 // uniform) and ALL stores.  A consumer issues the gather of step t, then finishes step t-1 (whose record was requested one
 // iteration earlier), so no wave ever waits on a load it has just issued.  One LDS-only barrier per step.
-struct PcSlot { unsigned w[256]; };      // record index | METH_STATUS << 24 | changed << 27
+struct PcSlot { unsigned w[256]; };      // record index | METH_STATUS << 24 | changed << 27 | current action << 28 | hot_cold << 31
 
 template <typename OUT>
 struct PcMarket {
@@ -1353,10 +1354,11 @@ __device__ __forceinline__ void pc_load_next(const HotParams& P, unsigned hb4, u
     X.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
 }
 
-template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT>
+template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT, bool INFO = false>
 __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
-             uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows)
+             uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows,
+             double* __restrict__ info)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT, SPLIT = LAY == PTG_OBS_SPLIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -1526,6 +1528,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     }
     const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * B;
     char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of the step being finished
+    double* info_t = info;
     // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
     // stores and the gathers just issued -- once per step, which serialises exactly what this kernel overlaps
     auto handoff = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -1536,7 +1539,8 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         bool changed;
         const int ridx = hot_ints<NOISE>(P, L, lut, LDSLUT, R, act, e, changed);
         tk = ld_off<unsigned short>(rkey, (unsigned)ridx * 2u);
-        slot[it & 1].w[lx] = (unsigned)ridx | ((R.flags & 7u) << 24) | (changed ? (1u << 27) : 0u);
+        slot[it & 1].w[lx] = (unsigned)ridx | ((R.flags & 7u) << 24) | (changed ? (1u << 27) : 0u) |
+                             (((R.flags >> 12) & 7u) << 28) | (((R.flags >> 3) & 1u) << 31);       // + action, hot / cold: the info rows' fields
     };
     auto request = [&](const int t, rec_t& rec, unsigned& w) {                    // consumer: record gather of step t
         w = slot[t & 1].w[lx];
@@ -1557,9 +1561,24 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         }
         if (more) request(t + 1, recN, wN);
         const bool changed = (w >> 27) & 1u;
-        double rw = hot_reward(P, rec, M.el, M.gas, M.eua, setc.x);
+        double rw;
+        RewTerms rt;
+        if constexpr (sizeof(OUT) == 8) { rt = reward_ref(P.rc, rec.m[0], rec.m[1], rec.m[2], rec.m[3], rec.m[4], M.el, M.gas, M.eua, setc.x); rw = rt.rew; }
+        else rw = hot_reward(P, rec, M.el, M.gas, M.eua, setc.x);
         R.cum += rw;
         rw -= changed ? setc.y : 0.0;                                            // :332
+        if constexpr (INFO && sizeof(OUT) == 8) {           // its own instantiation: six inlined copies of these stores in every float64
+            if (info_t) {                                   // kernel cost 8 % at 20 steps per launch (instruction footprint).  _get_info (:251-278)
+                double* ir = info_t + (size_t)e * PTG_N_INFO;
+                ir[0] = (double)(k1 - 1); ir[1] = M.el; ir[2] = M.gas; ir[3] = M.eua;
+                ir[4] = (double)((w >> 24) & 7u); ir[5] = (double)((w >> 28) & 7u); ir[6] = (double)(w >> 31);
+                ir[7] = rec.T; ir[8] = rec.m[0]; ir[9] = rec.m[1]; ir[10] = rec.m[3]; ir[11] = rec.m[4];
+                ir[12] = rt.ch4_rev; ir[13] = rt.steam_rev; ir[14] = rt.o2_rev; ir[15] = rt.eua_rev; ir[16] = rt.chp_rev;
+                ir[17] = -rt.cost_heat; ir[18] = -rt.cost_elz; ir[19] = -rt.cost_water; ir[20] = rw; ir[21] = R.cum;
+                ir[22] = P.pot_raw[hb_cur]; ir[23] = P.pf_raw[hb_cur];
+                info_t += (size_t)P.N * PTG_N_INFO;
+            }
+        }
         if (P.track_changes) { if (changed && live) P.st_c[e].nchg += 1; }
         auto emit = [&](const auto& row) {
 #pragma unroll
@@ -1837,6 +1856,7 @@ struct ptg_env {
     const void* hs_seen[4] = {nullptr, nullptr, nullptr, nullptr}; void* hs_dev[4] = {nullptr, nullptr, nullptr, nullptr}; bool hs_zero_copy = false;
     int knob_chunk = 65536, knob_block = 0;
     // per-launch timing (ptg_profile): kernel-attached start / stop events of the launches since profiling was switched on
+    double* rollout_info = nullptr;   // set by ptg_rollout_info around its hot launches: the [T][N][24] info matrix (float64 kernels only)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_used, prof_free;
     std::string err;
@@ -2083,9 +2103,12 @@ HotParams make_hot_params(const ptg_env* h)
     F.flat = h->flat ? 1 : 0; F.track_changes = P.track_changes; F.key_cold_max = P.key_cold_max; F.key_hot_min = P.key_hot_min; F.key_standby_max = P.key_standby_max;
     F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride;
     F.off_featB = h->off_featB; F.off_gasn = h->off_gasn; F.off_euan = h->off_euan; F.off_sc = h->off_sc; F.off_gas = h->off_gas; F.off_eua = h->off_eua;
-    F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.noise_sigma = P.noise_sigma; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
+    F.noise_seed = P.noise_seed; F.env_offset = P.env_offset; F.k_chp = P.k_chp; F.k_eua = P.k_eua;
+    // no noise source configured (neither tape nor RNG): the draws are 0 -- the RNG kernels with sigma 0 (0 x finite = 0 exactly;
+    // the draw counter advances as in every mode), one third fewer kernel instantiations to build
+    F.noise_sigma = (P.tape_len > 0 || P.noise_inline) ? P.noise_sigma : 0.0;
     F.o64_featA = h->o64_featA; F.o64_featB = h->o64_featB; F.o64_gasn = h->o64_gasn; F.o64_euan = h->o64_euan; F.o64_sc = h->o64_sc;
-    F.rec = P.rec;
+    F.rec = P.rec; F.pot_raw = P.pot_raw; F.pf_raw = P.pf_raw;
     RewC& c = F.rc;
     c.c_mol = P.c_mol; c.Hu_ch4 = P.Hu_ch4; c.Hu_h2 = P.Hu_h2; c.dt_cp_evap = P.dt_cp_evap; c.heat_price = P.heat_price; c.o2_price = P.o2_price;
     c.eeg = P.eeg; c.eta_chp = P.eta_chp; c.one_m_eta_chp = P.one_m_eta_chp; c.M_co2 = P.M_co2; c.M_h2o = P.M_h2o; c.rho = P.rho;
@@ -2191,6 +2214,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
         OUT* o_s = obs + (size_t)ts * h->n * h->F;
         OUT* r_s = rew + (size_t)ts * h->n;
         uint8_t* d_s = done + (size_t)ts * h->n;
+        double* i_s = h->rollout_info ? h->rollout_info + (size_t)ts * h->n * PTG_N_INFO : nullptr;
         const int k0 = h->sync_k + ts;
         const int vec_rows = (h->n % 4 == 0) && ((uintptr_t)a_s % 16 == 0) && (chunk % 4 == 0);     // whole-row vector loads are aligned
         const size_t sh = fixed + 16 * (((size_t)tn * np + 15) / 16) + (ll ? lut_bytes : 0);
@@ -2208,12 +2232,22 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
             hipEvent_t pe0, pe1;                                                                                      \
             prof_pair(h, pe0, pe1);                                                                                   \
             hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)sh, st, pe0, pe1, 0, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, \
-                                  (const unsigned short*)h->d_lut16, (const unsigned short*)h->d_rkey, e0, vec_rows); \
+                                  (const unsigned short*)h->d_lut16, (const unsigned short*)h->d_rkey, e0, vec_rows, i_s); \
         } else                                                                                                        \
-            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows); \
+            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s); \
     } while (0)
 #define PTG_PC(LL) do { if (full) PTG_PC2(LL, true); else PTG_PC2(LL, false); } while (0)
-            if (ll) PTG_PC(true); else PTG_PC(false);
+            bool launched = false;
+            if constexpr (std::is_same<OUT, double>::value) {
+                if (i_s) {                                  // the eval info stream: one variant (lookup in global memory, any batch size)
+                    auto kfn = k_rollout_pc<LAY, MOD, NOISE, false, false, double, true>;
+                    static int attr_dev_i = -1;
+                    if (attr_dev_i != h->device) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_dev_i = h->device; }
+                    hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s);
+                    launched = true;
+                }
+            }
+            if (!launched) { if (ll) PTG_PC(true); else PTG_PC(false); }
 #undef PTG_PC
 #undef PTG_PC2
         }
@@ -2223,8 +2257,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
 #define PTG_HOT_DISPATCH3(FN, LAY_, OUT_, ...)                                                           \
     do {                                                                                                \
         if (nm_ == NOISE_TAPE) { if (mod_) FN<LAY_, true, NOISE_TAPE, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_TAPE, OUT_>(__VA_ARGS__); }      \
-        else if (nm_ == NOISE_RNG) { if (mod_) FN<LAY_, true, NOISE_RNG, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_RNG, OUT_>(__VA_ARGS__); }    \
-        else { if (mod_) FN<LAY_, true, NOISE_NONE, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_NONE, OUT_>(__VA_ARGS__); }                        \
+        else { if (mod_) FN<LAY_, true, NOISE_RNG, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_RNG, OUT_>(__VA_ARGS__); }   /* no noise source = the RNG kernels with sigma 0 (make_hot_params) */ \
     } while (0)
 // obs / rew arrive as void*: the element type is the handle's out_dtype (SB3_FLAT rows are float32 only, see hot_eligible)
 #define PTG_HOT_DISPATCH(FN, H_, ST_, A_, KIND_, CNT_ARGS_, OBS_, REW_, DONE_)                           \
@@ -2634,13 +2667,13 @@ static int launch_step_generic(ptg_env* h, hipStream_t st, const void* actions_d
 // generic rollout = T generic step launches (measured faster than a fused generic kernel, whose register pressure spills):
 // float64 outputs, unusual price_ahead, de-synchronised batches, and the one terminating step per episode take this route
 static int launch_rollout_generic(ptg_env* h, hipStream_t st, const void* actions_dev, int action_kind, int n_steps, void* obs_dev,
-                                  void* rew_dev, uint8_t* done_dev)
+                                  void* rew_dev, uint8_t* done_dev, double* info_dev = nullptr)
 {
     const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
     for (int t = 0; t < n_steps; t++) {
         const int rc = launch_step_generic(h, st, (const char*)actions_dev + (size_t)t * h->n * asz, action_kind,
                                            (char*)obs_dev + (size_t)t * h->n * h->F * osz, (char*)rew_dev + (size_t)t * h->n * osz,
-                                           done_dev + (size_t)t * h->n, nullptr, nullptr);
+                                           done_dev + (size_t)t * h->n, nullptr, info_dev ? info_dev + (size_t)t * h->n * PTG_N_INFO : nullptr);
         if (rc) return rc;
     }
     return 0;
@@ -2668,38 +2701,44 @@ int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev
     return rc;
 }
 
-int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
-                uint8_t* done_dev, void* stream)
+// ptg_rollout / ptg_rollout_info: hot segments between the (rare) terminating steps; generic kernels for everything else.  Info rows
+// come out of the fused kernel for float64 outputs (it evaluates the reference-order reward terms anyway), else of generic steps.
+static int rollout_impl(ptg_env* h, const char* what, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
+                        uint8_t* done_dev, double* info_dev, void* stream)
 {
     if (!h) return PTG_E_INVALID;
-    if (!actions_dev || !obs_dev || !rew_dev || !done_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "ptg_rollout: bad argument");
-    if (action_kind < PTG_ACT_I32 || action_kind > PTG_ACT_I64) return set_err(h, PTG_E_INVALID, "ptg_rollout: bad action_kind");
+    if (!actions_dev || !obs_dev || !rew_dev || !done_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "%s: bad argument", what);
+    if (action_kind < PTG_ACT_I32 || action_kind > PTG_ACT_I64) return set_err(h, PTG_E_INVALID, "%s: bad action_kind", what);
     if ((h->cfg.action_type == 1) != (action_kind == PTG_ACT_F32))
-        return set_err(h, PTG_E_INVALID, "ptg_rollout: action_kind does not match cfg.action_type");
-    if (!h->reset_done) return set_err(h, PTG_E_INVALID, "ptg_rollout: envs must be reset first");
+        return set_err(h, PTG_E_INVALID, "%s: action_kind does not match cfg.action_type", what);
+    if (!h->reset_done) return set_err(h, PTG_E_INVALID, "%s: envs must be reset first", what);
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = as_stream(stream);
     const int k_term = h->cfg.eps_sim_steps - 6;
     const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
+    const bool hot_ok_info = !info_dev || h->cfg.out_dtype == PTG_OUT_F64;
     int t0 = 0;
-    while (t0 < n_steps) {          // hot segments between the (rare) terminating steps; generic kernels for everything else
+    while (t0 < n_steps) {
         const char* a_t = (const char*)actions_dev + (size_t)t0 * h->n * asz;
         char* o_t = (char*)obs_dev + (size_t)t0 * h->n * h->F * osz;
         char* r_t = (char*)rew_dev + (size_t)t0 * h->n * osz;
         uint8_t* d_t = done_dev + (size_t)t0 * h->n;
+        double* i_t = info_dev ? info_dev + (size_t)t0 * h->n * PTG_N_INFO : nullptr;
         int rc = 0, cnt;
-        if (hot_eligible(h) && h->sync_k != k_term) {
+        if (hot_eligible(h) && hot_ok_info && h->sync_k != k_term) {
             cnt = std::min(n_steps - t0, k_term - h->sync_k);
+            h->rollout_info = i_t;
             PTG_HOT_DISPATCH(launch_rollout_hot, h, st, a_t, action_kind, PTG_COMMA_ARG(cnt), o_t, r_t, d_t);
+            h->rollout_info = nullptr;
             rc = launch_check(h, "k_rollout_pc");
             h->sync_k += cnt;
-        } else if (h->sync_k >= 0) {                            // the terminating step of a synchronised batch
+        } else if (h->sync_k >= 0) {                            // the terminating step of a synchronised batch (or a float32 info stream)
             cnt = 1;
-            rc = launch_rollout_generic(h, st, a_t, action_kind, 1, o_t, r_t, d_t);
+            rc = launch_rollout_generic(h, st, a_t, action_kind, 1, o_t, r_t, d_t, i_t);
             h->sync_k = (h->sync_k == k_term) ? 0 : h->sync_k + 1;
         } else {
             cnt = n_steps - t0;
-            rc = launch_rollout_generic(h, st, a_t, action_kind, cnt, o_t, r_t, d_t);
+            rc = launch_rollout_generic(h, st, a_t, action_kind, cnt, o_t, r_t, d_t, i_t);
         }
         if (rc) return rc;
         t0 += cnt;
@@ -2707,19 +2746,17 @@ int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_step
     return 0;
 }
 
+int ptg_rollout(ptg_env* h, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
+                uint8_t* done_dev, void* stream)
+{
+    return rollout_impl(h, "ptg_rollout", actions_dev, action_kind, n_steps, obs_dev, rew_dev, done_dev, nullptr, stream);
+}
+
 int ptg_rollout_info(ptg_env* h, const void* actions_dev, int action_kind, int n_steps, void* obs_dev, void* rew_dev,
                      uint8_t* done_dev, double* info_dev, void* stream)
 {
-    if (!h) return PTG_E_INVALID;
-    if (!actions_dev || !obs_dev || !rew_dev || !done_dev || !info_dev || n_steps < 1) return set_err(h, PTG_E_INVALID, "ptg_rollout_info: bad argument");
-    const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
-    for (int t = 0; t < n_steps; t++) {                     // info rows need the un-reduced reward terms: the generic step kernel, T launches
-        const int rc = ptg_step(h, (const char*)actions_dev + (size_t)t * h->n * asz, action_kind, (char*)obs_dev + (size_t)t * h->n * h->F * osz,
-                                (char*)rew_dev + (size_t)t * h->n * osz, done_dev + (size_t)t * h->n, nullptr,
-                                info_dev + (size_t)t * h->n * PTG_N_INFO, stream);
-        if (rc) return rc;
-    }
-    return 0;
+    if (h && !info_dev) return set_err(h, PTG_E_INVALID, "ptg_rollout_info: bad argument");
+    return rollout_impl(h, "ptg_rollout_info", actions_dev, action_kind, n_steps, obs_dev, rew_dev, done_dev, info_dev, stream);
 }
 
 int ptg_rollout_launches(ptg_env* h, int n_steps)
