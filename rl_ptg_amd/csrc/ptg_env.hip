@@ -1354,6 +1354,14 @@ __device__ __forceinline__ void pc_load_next(const HotParams& P, unsigned hb4, u
     X.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
 }
 
+#ifdef PTG_STAMPS      // diagnostic build (tools/stamps.py): 100 MHz wall-clock stamps of the phases of a launch, per workgroup and role
+__device__ unsigned long long g_stamps[256][2][8];
+#define PTG_STAMP(slot_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && ((threadIdx.x >> 6) == 0 || (int)(threadIdx.x >> 6) == (NP >> 6))) \
+        g_stamps[blockIdx.x][(threadIdx.x >> 6) == 0 ? 0 : 1][slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PTG_STAMP(slot_) do {} while (0)
+#endif
+
 template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT, bool INFO = false>
 __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
@@ -1364,6 +1372,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const int NP = blockDim.x / 2;                          // envs per workgroup (64, 128 or 256): NP producer lanes, NP consumer lanes
     const int nwork = blockDim.x;
+    PTG_STAMP(0);
     HotLds& L = *(HotLds*)s_dyn;
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
     typedef typename HotTypes<OUT>::rec_t rec_t;
@@ -1467,6 +1476,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         else stage(std::integral_constant<int, PTG_ACT_I32>{});
         if (__ballot(bad_any)) { if (bad_any) P.err[0] = 1; }
     }
+    PTG_STAMP(1);
     hot_stage_lds(P, L);
     if (LDSLUT) {                       // 16-byte pieces, four loads in flight per lane (the lookup is padded to whole pieces)
         const int n16 = (N_DEST * P.nT * 2 + 15) / 16, bd = nwork;
@@ -1480,7 +1490,9 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
             for (int u = 0; u < 4; u++) { const int q = q0 + u * bd; if (q < n16) dst[q] = v[u]; }
         }
     }
+    PTG_STAMP(2);
     __syncthreads();
+    PTG_STAMP(3);
     const unsigned short* lut = LDSLUT ? s_lut : nullptr;
     const unsigned mset = (R.flags >> 15) & 3;
     // series offsets of step count k1 for this env (:442-447); uniform except for the episode offset
@@ -1637,18 +1649,21 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     // backend's vmcnt bookkeeping sees only that role's loads and stores (a shared loop with the roles as exec-masked regions
     // made it drain the whole queue at the top of every consumer iteration).
     if (producer) {
-        for (int it = 0; it < T; it++) { produce(it); handoff(); }
+        for (int it = 0; it < T; it++) { produce(it); handoff(); if (it == 0) PTG_STAMP(4); if (it == 1) PTG_STAMP(5); }
+        PTG_STAMP(6);
         handoff();
     } else {
         handoff();
         request(0, recA, wA);
         handoff();
+        PTG_STAMP(4);
         if (T == 1) {
             finish(0, recA, wA, false, recB, wB);
         } else {
             // the first finish is peeled so that the loop is entered in the state its back edge leaves (a gather followed by
             // a step's stores): the backend then derives the exact vmcnt for "record landed", not the prologue's small one
             finish(0, recA, wA, true, recB, wB);
+            PTG_STAMP(5);
             handoff();
             int it = 3;
             for (; it + 1 <= T; it += 2) {                  // two steps per trip: the records ping-pong, no register copies
@@ -1666,6 +1681,10 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
             }
         }
     }
+#ifdef PTG_STAMPS
+    if (producer) PTG_STAMP(7);
+    else { PTG_STAMP(6); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PTG_STAMP(7); }
+#endif
     if (producer) {                                         // (shadow lanes: the same values to env N - 1's slots)
         R.flags = (R.flags & 0x1FFFFu) | (tk << 17);
         StA na; na.i = R.i; na.j = R.j; na.k = k0 + T; na.flags = R.flags;
@@ -3133,6 +3152,10 @@ int ptg_market_feature_series(ptg_env* h, int which, float* out_host, int cap, i
     }
     return 0;
 }
+
+#ifdef PTG_STAMPS
+int ptg_debug_stamps(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+#endif
 
 int ptg_debug_get_index_lut(ptg_env* h, double* T_values_host, int32_t* lut_host, int* n_T)
 {

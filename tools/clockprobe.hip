@@ -41,9 +41,24 @@ __global__ void __launch_bounds__(256) k_read(const vf4* p, size_t n4, float* si
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
 }
 
+// entry skew of a grid: every workgroup stamps the 100 MHz clock when its first wave starts (and uses `vregs`-ish registers / LDS as asked)
+__global__ void k_entry(unsigned long long* out)
+{
+    extern __shared__ unsigned char dyn[];
+    if (threadIdx.x == 0) { out[blockIdx.x] = __builtin_amdgcn_s_memrealtime(); if (dyn[0] == 123) out[blockIdx.x] = 0; }
+}
+
 }  // namespace
 
 extern "C" {
+
+int entry_probe(void* stream, unsigned long long* out_dev, int n_wg, int block, int lds_bytes)
+{
+    (void)hipFuncSetAttribute((const void*)k_entry, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    hipLaunchKernelGGL(k_entry, dim3(n_wg), dim3(block), lds_bytes, (hipStream_t)stream, out_dev);
+    return (int)hipGetLastError();
+}
+
 
 int clk_probe(void* stream, unsigned long long* out_dev, int n_wg, int spin_cycles)
 {
