@@ -2972,6 +2972,11 @@ int ptg_profile(ptg_env* h, int enable)
     if (enable && !h->profiling) {                          // a fresh collection
         for (auto& p : h->prof_used) h->prof_free.push_back(p);
         h->prof_used.clear();
+        while (h->prof_free.size() < 16) {                  // event pairs created here, not inside the first timed launch
+            std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
+            if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) { (void)hipGetLastError(); break; }
+            h->prof_free.push_back(p);
+        }
     }
     h->profiling = enable != 0;
     return 0;
