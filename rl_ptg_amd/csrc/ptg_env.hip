@@ -2653,8 +2653,10 @@ int ptg_reset(ptg_env* h, const uint8_t* mask_host, void* obs_dev, void* stream)
     int rc = launch_check(h, "k_reset");
     if (d_mask) { (void)hipStreamSynchronize(st); (void)hipFree(d_mask); }
     if (rc) return rc;
-    if (!mask_host) { h->reset_done = true; h->sync_k = 0; }
-    else h->sync_k = -1;                                 // a partial reset de-synchronises the batch
+    bool all = !mask_host;
+    if (mask_host) { all = true; for (int e = 0; e < h->n && all; e++) all = mask_host[e] != 0; }
+    if (all) { h->reset_done = true; h->sync_k = 0; }      // (a mask that selects every env is a full reset)
+    else h->sync_k = -1;                                 // a partial reset de-synchronises the batch: generic kernels from here on
     return 0;
 }
 
