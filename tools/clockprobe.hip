@@ -48,9 +48,37 @@ __global__ void k_entry(unsigned long long* out)
     if (threadIdx.x == 0) { out[blockIdx.x] = __builtin_amdgcn_s_memrealtime(); if (dyn[0] == 123) out[blockIdx.x] = 0; }
 }
 
+// a chain of dependent launches of the step kernel's shape (256 x 256 threads): what does ONE launch cost at least when it
+// moves `n16` 16-byte pieces (kind 1: written; kind 2: one sixth read first, the rest written) -- or nothing at all (kind 0)?
+__global__ void __launch_bounds__(256) k_chain(vf4* p, const vf4* q, size_t n16, int kind)
+{
+    if (kind == 0) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, g0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    vf4 x = {1.f, 2.f, 3.f, 4.f};
+    if (kind == 2) for (size_t g = g0; g < n16 / 6; g += stride) x += q[g];
+    for (size_t g = g0; g < n16; g += stride) __builtin_nontemporal_store(x, p + g);
+}
+
 }  // namespace
 
 extern "C" {
+
+double chain_probe(void* buf, void* buf2, size_t bytes, int kind, int n_launch)
+{
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess) return -1.0;
+    hipGraph_t g; hipGraphExec_t ge; hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < n_launch; i++) hipLaunchKernelGGL(k_chain, dim3(256), dim3(256), 0, st, (vf4*)buf, (const vf4*)buf2, bytes / 16, kind);
+    if (hipStreamEndCapture(st, &g) != hipSuccess || hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) return -2.0;
+    (void)hipGraphLaunch(ge, st); (void)hipStreamSynchronize(st);       // warm
+    (void)hipEventRecord(e0, st); (void)hipGraphLaunch(ge, st); (void)hipEventRecord(e1, st); (void)hipStreamSynchronize(st);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+    return (double)ms * 1e3 / n_launch;
+}
 
 int entry_probe(void* stream, unsigned long long* out_dev, int n_wg, int block, int lds_bytes)
 {
