@@ -102,7 +102,9 @@ def cpu_baseline(spec, n_envs=131072, n_steps=105, seed=7):
             # the reference's own Python cannot travel to the GPU box; its figure is the survey's, reported only
             "reference_python": {"value": [1.0e4, 1.8e4], "unit": "env-steps/s per core", "measured_in_this_run": False,
                                  "host": "build container, 1 of 8 vCPU Intel Xeon @ 2.10 GHz, unmodified env/ptg_gym_env.py, 1 env",
-                                 "source": "BASELINE.md section 3 (random actions 1.03e4 ... held actions 1.79e4)"}}
+                                 "source": "BASELINE.md section 3 (random actions 1.03e4 ... held actions 1.79e4)",
+                                 "published_pipeline_fps": 166,      # the reference's only published figure: SB3 time/fps of a whole PPO run
+                                 }}
 
 
 def main():
