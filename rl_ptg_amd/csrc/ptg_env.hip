@@ -1397,6 +1397,22 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     const StA a = P.st_a[e]; const StB b = P.st_b[e];
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
+    if (LDSLUT) {
+        // The 58 KB lookup goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1 KiB row per wave instruction, no register
+        // round trip, nothing to wait for before the barrier's own vmcnt(0)); the 32 workgroups of an XCD start at different rows so
+        // that they do not walk the same L2 channel in lock-step.  Issued BEFORE the action rows are requested: the two latencies overlap.  (Staged through registers, four 16-byte loads in flight per
+        // lane, this copy took 2.7 us of every launch: in-kernel stamps, profiles/r02_tsweep.txt.)
+        const int n16 = (N_DEST * P.nT * 2 + 15) / 16, rows = (n16 + 63) / 64;
+        const int wave = threadIdx.x >> 6, nw = nwork >> 6, lane = threadIdx.x & 63;
+        const int rot = (int)(((blockIdx.x >> 3) & 31u) * (unsigned)(rows / 32));
+        for (int r0 = wave; r0 < rows; r0 += nw) {
+            int r = r0 + rot;
+            r = r >= rows ? r - rows : r;
+            const uint4* src = (const uint4*)lut16 + min(r * 64 + lane, n16 - 1);      // the last row's spare lanes re-read the last piece
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)((unsigned char*)s_lut + (size_t)r * 1024), 16, 0, 0);
+        }
+    }
     // The whole launch's action rows are staged into LDS up front, decoded to one byte each (7 = "keep the previous action":
     // no threshold fired, :351-355, or an invalid discrete action, which also raises the error flag).  A fresh action row
     // comes from HBM; fetched step by step its latency under the write stream -- vmcnt retires in order, so one slow load holds
@@ -1478,18 +1494,6 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     }
     PTG_STAMP(1);
     hot_stage_lds(P, L);
-    if (LDSLUT) {                       // 16-byte pieces, four loads in flight per lane (the lookup is padded to whole pieces)
-        const int n16 = (N_DEST * P.nT * 2 + 15) / 16, bd = nwork;
-        const uint4* src = (const uint4*)lut16;
-        uint4* dst = (uint4*)s_lut;
-        for (int q0 = threadIdx.x; q0 < n16; q0 += 4 * bd) {
-            uint4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = src[min(q0 + u * bd, n16 - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int q = q0 + u * bd; if (q < n16) dst[q] = v[u]; }
-        }
-    }
     PTG_STAMP(2);
     __syncthreads();
     PTG_STAMP(3);
@@ -2178,7 +2182,7 @@ PcPlan pc_plan(const ptg_env* h)
         pl.chunk = std::max(256, ((h->n + slices - 1) / slices + 255) / 256 * 256);
     }
     pl.fixed = 16 * ((sizeof(HotLds) + 15) / 16) + 2 * sizeof(PcSlot);     // + the row-major tiles, below
-    pl.lut_bytes = 16 * (((size_t)N_DEST * h->Tvals.size() * 2 + 15) / 16);
+    pl.lut_bytes = 1024 * ((((size_t)N_DEST * h->Tvals.size() * 2 + 15) / 16 + 63) / 64);      // whole 1 KiB rows (k_rollout_pc's LDS-DMA staging)
     pl.lds_max = 160 * 1024 - 512;
     // half producers, half consumers: the smallest workgroup (64, 128 or 256 envs) whose grid still fits the chip in ONE round of
     // workgroups (one per CU: the LDS stage allows no second one) -- small batches spread over many CUs, large ones do not queue
