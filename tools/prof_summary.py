@@ -16,9 +16,10 @@ LAY = {"0": "row", "1": "feature", "2": "sb3_flat", "3": "split"}
 
 
 def short(name):
-    m = re.search(r"(k_rollout_pc|k_step_hot)<(\d)[^>]*?(float|double)>", name)
+    m = re.search(r"(k_rollout_pc|k_step_hot)<(\d)[^>]*?(float|double)(, (?:true|false))?>", name)
     if m:
-        return f"{m.group(1)}<{LAY[m.group(2)]}>" if m.group(3) == "float" else f"{m.group(1)}<{LAY[m.group(2)]},f64>"
+        tag = LAY[m.group(2)] + ("" if m.group(3) == "float" else ",f64") + (",info" if m.group(4) == ", true" else "")
+        return f"{m.group(1)}<{tag}>"
     for k in ("k_refresh", "k_extract_keys", "k_step", "k_reset", "k_build_records", "k_build_argmin", "k_build_fast", "k_fill_noise", "k_init_state", "k_zero_noise_count"):
         if k in name:
             return k
@@ -72,6 +73,22 @@ for k in sorted(trace):
         lines.append(f"`{k}` dispatches in order [us]: " + ", ".join(f"{x / 1e3:.1f}" for x in d) +
                      (f"  -> timed {K}-step launch: **{d[1] / 1e3:.1f} us** = {d[1] / 1e3 / K:.3f} us per step" if len(d) > 1 else "") +
                      (f"; second 400-step steady rollout: {sum(d[2 + (len(d) - 2) // 2:]) / 1e3:.1f} us = {sum(d[2 + (len(d) - 2) // 2:]) / 1e3 / 400:.3f} us per step" if len(d) > 3 else ""))
+# the bench line of the PROFILED run: its own event-based figures for the same launches
+try:
+    line = [l for l in open(f"gpurun_out/prof_{tag}_trace.log") if l.startswith("{")][-1]
+    bj = json.loads(line)
+    legs = [("headline (row-major float32)", bj["roofline"])] + [(k, v["roofline"]) for k, v in bj.get("also", {}).items()]
+    lines += ["", "bench.py's own figures in this same profiled run (HIP events attached to the launches).  Two things to know when comparing: (i) with the",
+              "profiler attached the event pair reads 4-7 us MORE than the dispatch duration above (tools/tsweep.py under rocprofv3: 10.5-15.9 vs 6.5-7.2 us at",
+              "T = 1, 37-40 vs 33-37 at T = 20), without it the events match these dispatch durations (6.3-6.6 us at T = 1, 33-35 at T = 20); (ii) the whole",
+              "profiled process runs 8-10 % slower than an un-profiled one (steady state 1.60-1.65 vs 1.47-1.53 us per step; MI355X_MICROARCH.md, DVFS",
+              "give-back item 2: never compare a profiled arm with an un-profiled one).  The un-profiled driver-argument run is profiles/r02_bench_driver_args.json."]
+    for nme, r in legs:
+        lines.append(f"* {nme}: avg_launch_us = {r['avg_launch_us']:.2f} over {r['launches_timed']} launch(es), frac = {r['frac']:.3f}")
+    if "steady_state" in bj:
+        lines.append(f"* steady_state: {bj['steady_state']['us_per_step']:.3f} us per step, frac = {bj['steady_state']['frac']:.3f}")
+except Exception as e:
+    lines += ["", f"(no bench line found in gpurun_out/prof_{tag}_trace.log: {e})"]
 traffic = {"source": f"profiles/{tag}_summary.md"}
 lines += ["", "| kernel | dispatch | FETCH_SIZE KiB (raw) | read bytes (x2 corrected) | WRITE_SIZE KiB | HBM bytes | per step / launch |", "|---|---|---|---|---|---|---|"]
 for k in sorted(pmc):
@@ -81,6 +98,8 @@ for k in sorted(pmc):
     ws = [v for _, v in sorted(pmc[k].get("WRITE_SIZE", []))]
     layout = k[k.index("<") + 1:-1]
     dt = "float32"
+    if layout.endswith(",info"):
+        continue
     if layout.endswith(",f64"):
         layout, dt = layout[:-4], "float64"
     if k.startswith("k_rollout_pc") and len(fs) > 1 and len(ws) > 1:
