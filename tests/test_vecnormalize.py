@@ -165,3 +165,48 @@ def test_vecenv_norm_reward_is_the_reference_wrapper():
     np.testing.assert_allclose(r1, np.clip(r0.astype(np.float64) / np.sqrt(st["var"] + 1e-8), -10, 10), rtol=2e-6, atol=1e-30)
     assert wrapped.ret_rms == st
     plain.close(); wrapped.close()
+
+
+@pytest.mark.gpu
+def test_vecenv_norm_reward_reset_and_frozen_statistics():
+    """(1) VecNormalize.reset() starts the discounted returns at zero again -- PtGVecEnv.reset() must too; (2) with
+    training = False the statistics are frozen and the returns are NOT advanced, but returns[dones] = 0 still happens.  Checked
+    against the restated SB3 algorithm (oracle/vecnormalize_oracle.py; unpinned against SB3 itself)."""
+    from rl_ptg_amd.prep import synthetic_spec
+    from rl_ptg_amd.vec_env import PtGVecEnv
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=1, train_steps=200000)
+    n = 16
+    env = PtGVecEnv(spec, n_envs=n, seed=9, noise="device", norm_reward=True)
+    ora = vo.RewardNormalizer(n)
+    env.reset()
+    rng = np.random.default_rng(2)
+    for t in range(20):
+        a = rng.integers(0, 5, n)
+        _, r, d, _ = env.step(a)
+        ora.step(env.get_original_reward().astype(np.float64), d)
+    _, ret = env.engine.vn_get()
+    np.testing.assert_allclose(ret, ora.returns, rtol=1e-6, atol=1e-6)
+    assert np.abs(ret).max() > 0
+    env.reset()                                           # (1)
+    _, ret = env.engine.vn_get()
+    assert np.array_equal(ret, np.zeros(n))
+    ora.returns[:] = 0.0
+    # (2) frozen statistics across an episode end (139-step episodes): run up to the termination with training on, then freeze
+    for t in range(130):
+        a = rng.integers(0, 5, n)
+        _, r, d, _ = env.step(a)
+        ora.step(env.get_original_reward().astype(np.float64), d)
+    env.training = False
+    ora.training = False
+    stats = env.ret_rms
+    seen_done = False
+    for t in range(15):
+        a = rng.integers(0, 5, n)
+        _, r, d, _ = env.step(a)
+        exp = ora.step(env.get_original_reward().astype(np.float64), d)
+        np.testing.assert_allclose(r, exp, rtol=2e-6, atol=1e-30)
+        seen_done |= bool(d.any())
+        _, ret = env.engine.vn_get()
+        np.testing.assert_allclose(ret, ora.returns, rtol=1e-6, atol=1e-6)      # unchanged except zeroed where an episode ended
+    assert seen_done and env.ret_rms == stats
+    env.close()
