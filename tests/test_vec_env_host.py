@@ -140,3 +140,37 @@ def test_vec_env_checkpoint_resume_numpy_noise():
         ro, rr, rd, _ = ref[t - 30]
         assert all(np.array_equal(o[k], ro[k]) for k in o) and np.array_equal(r, rr) and np.array_equal(d, rd), t
     env2.close()
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    """50 handles created, used (reset, a hot rollout with its refresher stream, a host step, profiling events) and destroyed: the
+    device's free memory returns to where it was (tables, staging buffers, streams and events are all released)."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    spec = _spec()
+    torch.cuda.synchronize()
+    acts = np.random.default_rng(0).integers(0, 5, (8, 512)).astype(np.int32)
+
+    def cycle():
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, 512, device=0, out_dtype="float32", obs_layout="row")
+        eng.set_episode_plan(spec.eps_ind, 512, 512)
+        eng.set_noise_rng(1)
+        eng.reset()
+        eng.profile(True)
+        o, r, d = eng.rollout(acts)
+        eng.step(acts[0])
+        eng.sync()
+        assert len(eng.profile_read()) == 2
+        del o, r, d
+        eng.close()
+    for _ in range(3):
+        cycle()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(50):
+        cycle()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < (32 << 20), (free0, free1)
