@@ -1,0 +1,78 @@
+"""Batch sizes at every wave / workgroup boundary: the hot kernels (shadow lanes past N, partial row-tile flushes) write exactly
+their own output rows -- canary words on both sides of every output buffer stay untouched -- and agree bit for bit with the
+generic kernels on the same actions and noise stream.  (The reference has no batch dimension; its DummyVecEnv runs 6 envs,
+src/rl_utils.py:448-453 -- these sizes are the edge cases of THIS path's own geometry.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 6, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 777]
+T = 37
+
+
+def _guarded(torch, shape, dtype, dev, guard=512):
+    """A tensor of `shape` carved out of a larger canary-filled allocation: returns (view, whole, guard elements)."""
+    numel = int(np.prod(shape))
+    whole = torch.full((numel + 2 * guard,), 113, dtype=dtype, device=dev)
+    return whole[guard:guard + numel].view(shape), whole, guard
+
+
+def _canaries_intact(whole, guard):
+    w = whole.cpu().numpy()
+    return bool((w[:guard] == 113).all() and (w[-guard:] == 113).all())
+
+
+def _run(spec, n, layout, out_dtype, acts, route):
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    env = {"PTG_NO_HOT_KERNELS": "1"} if route == "generic" else {}
+    os.environ.update(env)
+    try:
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=out_dtype, obs_layout=layout)
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        eng.set_noise_rng(11)
+        eng.reset()
+        dev = torch.device("cuda", 0)
+        F = eng.obs_dim
+        oshape = (T, F, n) if eng.feature_major else (T, n, F)
+        obs, obs_w, g = _guarded(torch, oshape, eng.out_dtype, dev)
+        rew, rew_w, _ = _guarded(torch, (T, n), eng.out_dtype, dev)
+        done, done_w, _ = _guarded(torch, (T, n), torch.uint8, dev)
+        if route == "steps":                                  # one launch per step (k_step_hot), each into its own guarded row
+            for t in range(T):
+                eng.step(acts[t], obs[t], rew[t], done[t], want_final=False)
+        else:
+            eng.rollout(acts, obs, rew, done)
+        eng.sync()
+        assert _canaries_intact(obs_w, g) and _canaries_intact(rew_w, g) and _canaries_intact(done_w, g), (route, n, layout, out_dtype)
+        out = (obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done.cpu().numpy().copy(),
+               {f: eng.get_state(f) for f in ("meth_state", "i", "j", "k", "current_action", "noise_count", "cum_rew")})
+        eng.close()
+        return out
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("layout,out_dtype", [("row", "float32"), ("feature", "float32"), ("sb3_flat", "float32"), ("split", "float32"),
+                                              ("row", "float64"), ("feature", "float64")])
+def test_batch_sizes_at_wave_and_workgroup_boundaries(layout, out_dtype):
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=8)
+    rng = np.random.default_rng(77)
+    for n in SIZES:
+        acts = rng.integers(0, 5, (T, n)).astype(np.int32)
+        hot = _run(spec, n, layout, out_dtype, acts, "rollout")
+        stp = _run(spec, n, layout, out_dtype, acts, "steps")
+        if layout == "split":                                 # the generic kernels do not write the split layout: hot rollout == hot steps
+            ref = stp
+        else:
+            ref = _run(spec, n, layout, out_dtype, acts, "generic")
+        for got, name in ((hot, "rollout"), (stp, "steps")):
+            for a, b, what in zip(got[:3], ref[:3], ("obs", "rew", "done")):
+                assert np.array_equal(a, b), (name, what, n, layout, out_dtype)
+            for f, v in ref[3].items():
+                assert np.array_equal(got[3][f], v), (name, f, n, layout, out_dtype)
