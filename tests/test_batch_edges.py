@@ -76,3 +76,18 @@ def test_batch_sizes_at_wave_and_workgroup_boundaries(layout, out_dtype):
                 assert np.array_equal(a, b), (name, what, n, layout, out_dtype)
             for f, v in ref[3].items():
                 assert np.array_equal(got[3][f], v), (name, f, n, layout, out_dtype)
+
+
+@pytest.mark.parametrize("n", [65537, 100000])
+def test_batches_wider_than_one_launch(n):
+    """More than 65 536 envs: the rollout is cut into equal slices (100 000 -> 2 x 50 176 with shadow lanes in the last workgroup);
+    same canaries, same bit-for-bit agreement with the generic kernels."""
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=3, operation="OP2", eps_len_d=8)
+    acts = np.random.default_rng(78).integers(0, 5, (T, n)).astype(np.int32)
+    hot = _run(spec, n, "row", "float32", acts, "rollout")
+    ref = _run(spec, n, "row", "float32", acts, "generic")
+    for a, b, what in zip(hot[:3], ref[:3], ("obs", "rew", "done")):
+        assert np.array_equal(a, b), (what, n)
+    for f, v in ref[3].items():
+        assert np.array_equal(hot[3][f], v), (f, n)
