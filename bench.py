@@ -173,7 +173,8 @@ def main():
         else:
             eng.fill_noise_tape(seed=20250614, per_env_len=min(max(K + W + 8, 64), 1024))
         extra = STEADY_T * 2 if (steady and path == "rollout") else 0
-        actions = sticky_actions_device(K + W + extra, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
+        again = K if (path == "step" and launch == "graph") else 0      # the graph leg's K steps once more, eagerly, for per-launch kernel times
+        actions = sticky_actions_device(K + W + extra + again, n, seed=1234 + rank, device=device, p_switch=args.p_switch)
         eng.reset()
         bufs = None
         if path == "rollout":
@@ -239,7 +240,15 @@ def main():
         if graph is None:
             launch_us = eng.profile_read()
             eng.profile(False)
-        res = {"elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "n_launch": n_launch, "n_fin": len(r_all), "F": F, "steady": None}
+        else:
+            # a replayed graph takes no kernel-attached events: the same K steps are launched once more, eagerly and OUTSIDE the timed
+            # region, for the kernel's own duration (what rocprofv3 --kernel-trace reports per dispatch); `value` stays the graph replay
+            eng.profile(True)
+            run(W + K, K)
+            launch_us = eng.profile_read()
+            eng.profile(False)
+        res = {"elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "n_launch": n_launch, "n_fin": len(r_all), "F": F, "steady": None,
+               "rerun": graph is not None}
         if extra:                                             # steady state: two more 400-step launches, the second one counted
             eng.profile(True)
             for q in range(2):
@@ -267,6 +276,9 @@ def main():
         if res["launch_us"] is not None and len(res["launch_us"]):
             per_launch_s = float(np.mean(res["launch_us"])) * 1e-6
             launches, how = len(res["launch_us"]), "HIP events attached to each timed kernel launch (ptg_profile)"
+            if res.get("rerun"):
+                how = ("HIP events attached to each kernel launch of an eager re-run of the same K steps right after the timed graph replay "
+                       "(a replayed graph takes no per-kernel events); graph replay incl. boundaries: %.2f us per launch" % (res["span_ms"] * 1e3 / res["n_launch"]))
         else:                                                 # graph replay: stream events around the K back-to-back launches
             launches = res["n_launch"]
             per_launch_s, how = res["span_ms"] * 1e-3 / launches, "HIP events around the replayed graph / launches (boundaries included)"
