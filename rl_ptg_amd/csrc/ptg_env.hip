@@ -1210,6 +1210,18 @@ __device__ __forceinline__ void hot_fetch(int actk, const void* actions, size_t 
     else ri = ((const int*)actions)[g];
 }
 
+#ifdef PTG_STAMPS      // diagnostic build (tools/stamps.py, tools/step_stamps.py): 100 MHz wall-clock stamps of the phases of a launch, per workgroup and role
+__device__ unsigned long long g_stamps[256][2][8];
+#define PTG_STAMP(slot_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && ((threadIdx.x >> 6) == 0 || (int)(threadIdx.x >> 6) == (NP >> 6))) \
+        g_stamps[blockIdx.x][(threadIdx.x >> 6) == 0 ? 0 : 1][slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ST_STAMP(slot_) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_stamps[blockIdx.x][0][slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ST_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PTG_STAMP(slot_) do {} while (0)
+#define ST_STAMP(slot_) do {} while (0)
+#define ST_DRAIN() do {} while (0)
+#endif
+
 // one vector step, no env terminates (host-guaranteed); lanes past N shadow env N-1 and store nothing
 // LAY: 0 row-major, 1 feature-major, 2 SB3_FLAT rows (the PTG_OBS_* values)
 template <int LAY, bool MOD, int NOISE, typename OUT>
@@ -1223,18 +1235,25 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
     const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e_raw < P.N;
     const int e = live ? e_raw : P.N - 1;
+    ST_STAMP(0);
     const StA a = P.st_a[e]; const StB b = P.st_b[e];     // state + action loads in flight while LDS is staged
     int ri = 0; float rf = 0.f;
     hot_fetch(actk, actions, (size_t)e, ri, rf);
     hot_stage_lds(P, L);
     __syncthreads();
+    ST_STAMP(1); ST_DRAIN(); ST_STAMP(2);
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const int act = hot_decode(actk, P, ri, rf, R.flags);
     HotLoads<OUT> Q;
     hot_front<MOD, NOISE, OUT>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
+    ST_STAMP(3);
     const OUT r = hot_back<OUT>(P, R, Q, setc, e, live);
+#ifdef PTG_STAMPS
+    if (r == (OUT)123456.789) ST_STAMP(7);                  // keeps stamp 4 behind the reward (the record has arrived)
+#endif
+    ST_STAMP(4);
     const int e_wave = __builtin_amdgcn_readfirstlane(e_raw);                 // the wave's first env
     if (!FM && e_wave < P.N) {                                                   // rows: through the wave's LDS tile, out as one block
         OUT* rows = obs + (size_t)e_wave * P.F;
@@ -1251,6 +1270,7 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
     StA na; na.i = R.i; na.j = R.j; na.k = k0 + 1; na.flags = R.flags;
     StB nb; nb.cum = R.cum; nb.act_d = R.act_d; nb.nctr = R.nctr;
     P.st_a[e] = na; P.st_b[e] = nb;
+    ST_STAMP(5); ST_DRAIN(); ST_STAMP(6);
 }
 
 // Producer / consumer form of the fused rollout ("split gather").  Half of every workgroup's waves (producers) run ONLY the
@@ -1354,13 +1374,6 @@ __device__ __forceinline__ void pc_load_next(const HotParams& P, unsigned hb4, u
     X.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
 }
 
-#ifdef PTG_STAMPS      // diagnostic build (tools/stamps.py): 100 MHz wall-clock stamps of the phases of a launch, per workgroup and role
-__device__ unsigned long long g_stamps[256][2][8];
-#define PTG_STAMP(slot_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && ((threadIdx.x >> 6) == 0 || (int)(threadIdx.x >> 6) == (NP >> 6))) \
-        g_stamps[blockIdx.x][(threadIdx.x >> 6) == 0 ? 0 : 1][slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PTG_STAMP(slot_) do {} while (0)
-#endif
 
 template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT, bool INFO = false>
 __global__ void __launch_bounds__(512)

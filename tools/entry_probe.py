@@ -8,7 +8,7 @@ P = C.CDLL(so)
 P.entry_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
 dev = torch.device("cuda", 0)
 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-for n_wg, block, lds in [(256, 512, 0), (256, 512, 65536), (256, 512, 100 * 1024), (256, 512, 150 * 1024), (512, 256, 75 * 1024), (1024, 128, 37 * 1024),
+for n_wg, block, lds in [(256, 256, 36 * 1024), (256, 128, 18 * 1024), (128, 256, 36 * 1024), (512, 64, 9 * 1024), (256, 64, 9 * 1024), (256, 256, 0), (256, 128, 0), (256, 512, 0), (256, 512, 65536), (256, 512, 100 * 1024), (256, 512, 150 * 1024), (512, 256, 75 * 1024), (1024, 128, 37 * 1024),
                          (256, 256, 150 * 1024), (1024, 256, 0), (256, 1024, 150 * 1024)]:
     res = []
     for rep in range(5):
