@@ -14,7 +14,8 @@ flags are resident in HBM; nothing crosses PCIe inside the timed region.
 Workload: BASELINE.json configs[2] -- N = 65 536 envs, BS1/OP1, synthetic 38-day trace (32-day episodes), 'mod'
 features, discrete sticky actions, in-kernel counter RNG for the state-change noise.
 
-Timing.  `value` is wall clock over the K timed steps (barrier + synchronize on both sides).  `roofline` uses the
+Timing.  `value` is wall clock over the K timed steps: barrier + synchronize, start, K steps + the finished-episode all-gather (on a
+stream of its own, beside the kernels), synchronize, stop, barrier; N > 1: the MAX of that over the ranks.  `roofline` uses the
 kernel's own duration: every timed launch carries a HIP event pair stamped at the kernel's begin and end
 (ptg_profile, hipExtLaunchKernelGGL) -- what rocprofv3 --kernel-trace reports for the dispatch -- because an event
 recorded from Python on an idle stream also counts the host's launch latency (20 us of the 55 us round 1 reported
@@ -148,13 +149,18 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     coll_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # PTG_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, barriers, the collectives) with ONE rank -- the rehearsal of the
+    # RCCL calls a one-GPU box allows (profiles/r02_bench_rccl_1rank.log)
+    multi = world > 1 or bool(os.environ.get("PTG_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    coll_stream = torch.cuda.Stream(device=device)
     K, W, n = args.steps, args.warmup, args.envs
     n_total = n * world
     spec, _ = synthetic_spec(scenario=args.scenario, operation=args.operation, eps_len_d=32)
@@ -201,7 +207,10 @@ def main():
         run(0, W)
         wev.record()
         r, l, _ = eng.finished_episodes()
-        ptg_dist.all_gather_finished(r, l, device=coll_device)
+        with torch.cuda.stream(coll_stream):
+            for _ in range(3):                                # (the first collectives on a stream cost 2.7 ms, 100 us, 70 us; then 58: tools/agcost.py)
+                ptg_dist.all_gather_finished(r, l, device=coll_device)
+        torch.cuda.synchronize()
         eng.sync()
         eng.profile_read()
         eng.profile(False)
@@ -218,22 +227,29 @@ def main():
         n_launch = eng.rollout_launches(K) if path == "rollout" else K        # kernel launches inside the timed region
         if graph is None:
             eng.profile(True)                                 # kernel-attached begin / end events on every timed launch
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         ev0.record()
+        tA = time.perf_counter()
         if graph is not None:
             graph.replay()
         else:
             run(W, K)
+        tB = time.perf_counter()
         ev1.record()
         r, l, _ = eng.finished_episodes()          # synchronises only if an episode can have ended; episodic-return reduction (one all-gather)
-        r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
+        tC = time.perf_counter()
+        with torch.cuda.stream(coll_stream):       # on a stream of its own: the collective runs beside the step kernels, not behind them
+            r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
+        tD = time.perf_counter()
         torch.cuda.synchronize()
-        if world > 1:
+        elapsed = time.perf_counter() - t_start    # this rank's time since the common start (barrier + synchronize); MAX over ranks below
+        if os.environ.get("PTG_BENCH_DEBUG"):
+            print("timed region pieces us: ev0 %.0f run %.0f ev1+fin %.0f gather %.0f sync %.0f total %.0f" % ((tA - t_start) * 1e6, (tB - tA) * 1e6, (tC - tB) * 1e6, (tD - tC) * 1e6, (time.perf_counter() - tD) * 1e6, elapsed * 1e6), file=sys.stderr)
+        if multi:
             dist.barrier()
-        elapsed = time.perf_counter() - t_start
         eng.sync()
         span_ms = ev0.elapsed_time(ev1)                       # stream events around the whole timed region (includes host launch latency)
         launch_us = None
@@ -258,7 +274,7 @@ def main():
             eng.profile(False)
             per = len(us) // 2
             res["steady"] = {"steps": STEADY_T, "launch_us": [float(u) for u in us[per:]]}
-        if world > 1:
+        if multi:
             dev_sum = float(np.sum(launch_us)) if launch_us is not None else span_ms * 1e3
             tmax = torch.tensor([elapsed, dev_sum], dtype=torch.float64, device=coll_device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -367,7 +383,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

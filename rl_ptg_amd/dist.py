@@ -30,11 +30,52 @@ def mixed_scenario_assignment(n_total, world_size, rank, n_sets):
     return (np.arange(lo, hi) % n_sets).astype(np.uint8)
 
 
+INLINE = 15          # finished episodes per rank that travel with the count in the first (usually only) collective
+
+_PINNED = {}         # (numel, dtype) -> pinned host staging tensor (device collectives only)
+
+
+def _pinned(numel, dtype, tag):
+    import torch
+    key = (numel, dtype, tag)
+    t = _PINNED.get(key)
+    if t is None:
+        t = _PINNED[key] = torch.empty(numel, dtype=dtype).pin_memory()
+    return t
+
+
+def _gather_rows(x, dev, group, world):
+    """x: CPU tensor [m, c], the same shape on every rank -> NumPy [world, m, c]: one collective.  On a GPU device the rows go
+    through pinned staging buffers with asynchronous copies and ONE stream synchronisation (no pageable copies)."""
+    import torch
+    import torch.distributed as dist
+    flat = x.reshape(-1)
+    if dev.type == "cuda":
+        src_h = _pinned(flat.numel(), flat.dtype, "src")
+        dst_h = _pinned(flat.numel() * world, flat.dtype, "dst")
+        src_h.copy_(flat)
+        src = src_h.to(dev, non_blocking=True)
+        out = torch.empty(flat.numel() * world, dtype=flat.dtype, device=dev)
+        dist.all_gather_into_tensor(out, src, group=group)
+        dst_h.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return dst_h.numpy().reshape((world,) + tuple(x.shape)).copy()
+    out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype)
+    try:
+        dist.all_gather_into_tensor(out.view(-1), flat.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):       # backend without the flat form
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        out = torch.stack(parts)
+    return out.numpy()
+
+
 def all_gather_finished(returns, lengths, device=None, group=None):
     """All-gather variable-length finished-episode lists over the process group.
 
-    Returns (returns_all, lengths_all) ordered by rank.  One collective for the counts and, only when some rank has
-    entries, one for the padded payload (float64 return + length packed as [max_count, 2]).  With no initialised process group this is the identity."""
+    Returns (returns_all, lengths_all) ordered by rank.  ONE collective in the common cases: every rank sends [count, then its
+    first INLINE (return, length) pairs] as 1 + 2 * INLINE float64; only when some rank finished more than INLINE episodes a second
+    collective carries the remainders (padded to the longest).  With no initialised process group this is the identity."""
     import torch
     import torch.distributed as dist
     returns = np.asarray(returns, dtype=np.float64)
@@ -42,31 +83,32 @@ def all_gather_finished(returns, lengths, device=None, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return returns, lengths
     world = dist.get_world_size(group)
-    dev = torch.device("cpu") if device is None else device
-
-    def gather_rows(x):                       # x [m, c] on every rank -> [world, m, c] on the host, one collective + one copy
-        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=dev)
-        try:
-            dist.all_gather_into_tensor(out.view(-1), x.reshape(-1), group=group)
-        except (RuntimeError, NotImplementedError, AttributeError):       # backend without the flat form
-            parts = [torch.empty_like(x) for _ in range(world)]
-            dist.all_gather(parts, x, group=group)
-            out = torch.stack(parts)
-        return out.cpu().numpy()
-
-    counts = gather_rows(torch.tensor([[len(returns)]], dtype=torch.int64, device=dev)).reshape(world).tolist()
-    m = max(counts)
-    if m == 0:                                # the common case between episode ends: one small collective in total
-        return returns[:0], lengths[:0]
-    payload = torch.zeros((m, 2), dtype=torch.float64)
-    if len(returns):
-        payload[:len(returns), 0] = torch.from_numpy(returns)
-        payload[:len(returns), 1] = torch.from_numpy(lengths.astype(np.float64))
-    bufs = gather_rows(payload.to(dev))
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    c = len(returns)
+    head = np.zeros((1, 1 + 2 * INLINE))
+    head[0, 0] = c
+    k = min(c, INLINE)
+    head[0, 1:1 + 2 * k:2] = returns[:k]
+    head[0, 2:2 + 2 * k:2] = lengths[:k]                    # episode lengths are far below 2**53: exact as float64
+    heads = _gather_rows(torch.from_numpy(head), dev, group, world)[:, 0, :]
+    counts = heads[:, 0].astype(np.int64)
+    m = int(counts.max()) - INLINE
+    rest = None
+    if m > 0:                                 # rare: a rank with more than INLINE finished episodes since the last call
+        payload = np.zeros((m, 2))
+        if c > INLINE:
+            payload[:c - INLINE, 0] = returns[INLINE:]
+            payload[:c - INLINE, 1] = lengths[INLINE:]
+        rest = _gather_rows(torch.from_numpy(payload), dev, group, world)
     r_all, l_all = [], []
-    for c, b in zip(counts, bufs):
-        r_all.append(b[:c, 0])
-        l_all.append(b[:c, 1].astype(np.int64))
+    for rk in range(world):
+        ck = int(counts[rk])
+        kk = min(ck, INLINE)
+        r_all.append(heads[rk, 1:1 + 2 * kk:2])
+        l_all.append(heads[rk, 2:2 + 2 * kk:2].astype(np.int64))
+        if ck > INLINE:
+            r_all.append(rest[rk, :ck - INLINE, 0])
+            l_all.append(rest[rk, :ck - INLINE, 1].astype(np.int64))
     return np.concatenate(r_all), np.concatenate(l_all)
 
 

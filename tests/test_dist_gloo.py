@@ -28,6 +28,12 @@ def _worker(rank, world, port, q):
         r = np.array([rank * 100.0 + i for i in range(rank + 2)])
         l = np.array([10 + i for i in range(rank + 2)])
         ra, la = ptg_dist.all_gather_finished(r, l)
+        # more than the inline capacity on one rank only (rank 1: 23 episodes, rank 0: 3): the second collective
+        r2 = np.array([rank * 1000.0 + i * 0.5 for i in range(rank * 20 + 3)])
+        l2 = np.array([100 + i for i in range(rank * 20 + 3)])
+        ra2, la2 = ptg_dist.all_gather_finished(r2, l2)
+        rz, lz = ptg_dist.all_gather_finished(np.zeros(0), np.zeros(0, np.int64))     # nobody finished anything
+        assert len(rz) == 0 and len(lz) == 0
         # reward-normalisation moments: rank r holds envs [r*5, r*5+3+2r) of a ragged split; merged = moments over all envs
         x = np.random.default_rng(42).normal(2.0, 3.0, (4, 8))[:, rank * 3:rank * 3 + 3 + 2 * rank]
         mom = np.stack([np.full(4, x.shape[1], float), x.mean(1), ((x - x.mean(1, keepdims=True)) ** 2).sum(1)], -1)
@@ -41,7 +47,7 @@ def _worker(rank, world, port, q):
         env = H.po.OracleVecEnv(consts, tables, market, n, ep_index0=first_ptr - n)   # constructor consumes n, reset the next n
         env.reset()
         ints, _ = env.state()
-        q.put((rank, ra.tolist(), la.tolist(), ints[:, 11].tolist(), (lo, hi), (first_ptr, stride), merged.tolist()))
+        q.put((rank, ra.tolist(), la.tolist(), ints[:, 11].tolist(), (lo, hi), (first_ptr, stride), merged.tolist(), ra2.tolist(), la2.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -59,8 +65,11 @@ def test_world_size_2_gloo():
         assert p.exitcode == 0
     exp_r = [0.0, 1.0, 100.0, 101.0, 102.0]
     allx = np.random.default_rng(42).normal(2.0, 3.0, (4, 8))
-    for rank, ra, la, act_d, rng, plan, merged in out:
+    exp_r2 = [i * 0.5 for i in range(3)] + [1000.0 + i * 0.5 for i in range(23)]
+    exp_l2 = [100 + i for i in range(3)] + [100 + i for i in range(23)]
+    for rank, ra, la, act_d, rng, plan, merged, ra2, la2 in out:
         assert ra == exp_r and la == [10, 11, 10, 11, 12]
+        assert ra2 == exp_r2 and la2 == exp_l2
         assert rng == (rank * 3, rank * 3 + 3) and plan == (6 + rank * 3, 6)
         merged = np.array(merged)                   # both ranks hold the moments of all 8 envs (3 on rank 0 + 5 on rank 1)
         assert merged[:, 0].tolist() == [8.0] * 4
