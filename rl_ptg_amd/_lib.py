@@ -9,7 +9,8 @@ ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "ptg_env.hip")
 HDR = os.path.join(ROOT, "include", "ptg_env.h")
 LIB_PATH = os.environ.get("PTG_LIB_PATH") or os.path.join(PKG, "lib", "libptg_env.so")      # PTG_LIB_PATH: an experiment build of the same source
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall"]
+N_PARTS = 7          # translation units of the parallel build: -DPTG_PART=0..6 (ptg_env.hip, "PTG_PART")
 
 N_TABLES, N_INFO = 17, 24
 ACT_I32, ACT_F32, ACT_I64 = 0, 1, 2
@@ -70,10 +71,34 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
+    jobs = int(os.environ.get("PTG_BUILD_JOBS", "0")) or min(N_PARTS, os.cpu_count() or 1)
+    if jobs <= 1:                                             # one translation unit: the whole file in one hipcc call
+        cmd = [hipcc] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH, SRC]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return LIB_PATH
+    # the same source compiled N_PARTS times, each time with a different share of the hot-kernel instantiations, `jobs` at a time
+    obj_dir = os.path.join(os.path.dirname(LIB_PATH), "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = [os.path.join(obj_dir, f"ptg_env_part{k}.o") for k in range(N_PARTS)]
+    cmds = [[hipcc] + HIPCC_FLAGS + ["-Wno-unused-function", f"-DPTG_PART={k}", "-c", "-o", objs[k], SRC] for k in range(N_PARTS)]
+    running, todo, failed = [], list(enumerate(cmds)), []
+    while todo or running:
+        while todo and len(running) < jobs:
+            k, cmd = todo.pop(0)
+            if verbose:
+                print(" ".join(cmd))
+            running.append((k, subprocess.Popen(cmd)))
+        k, proc = running.pop(0)
+        if proc.wait() != 0:
+            failed.append(k)
+    if failed:
+        raise RuntimeError(f"hipcc failed on part(s) {failed} of {SRC}")
+    link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
 
 

@@ -2167,6 +2167,12 @@ bool hot_eligible(const ptg_env* h)
 
 int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
 
+}  // namespace
+
+// The launchers of the hot kernels have external linkage: the build spreads their instantiations (6 layout x dtype combinations x
+// 2 feature sets x 2 noise sources, each a family of kernels) over several translation units compiled in parallel, see PTG_PART below.
+namespace ptg_hot __attribute__((visibility("hidden"))) {
+
 template <int LAY, bool MOD, int NOISE, typename OUT>
 void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, OUT* obs, OUT* rew, uint8_t* done)
 {
@@ -2179,6 +2185,10 @@ void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, 
     } else
         hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
 }
+
+}  // namespace ptg_hot
+
+namespace {
 
 // Launch geometry of the fused hot rollout.  One launch covers <= 65 536 envs (one 512-thread workgroup per CU) and as many
 // steps as its LDS action stage holds; larger batches / longer rollouts run as consecutive launches over env slices and
@@ -2235,6 +2245,10 @@ void launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
                        (const unsigned short*)h->d_rkey, (int)h->rec_total, passes, period);
 }
 
+}  // namespace
+
+namespace ptg_hot __attribute__((visibility("hidden"))) {
+
 template <int LAY, bool MOD, int NOISE, typename OUT>
 void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, int T, OUT* obs, OUT* rew, uint8_t* done)
 {
@@ -2289,6 +2303,46 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
         }
     }
 }
+
+}  // namespace ptg_hot
+
+// PTG_PART (the parallel build, rl_ptg_amd/_lib.py): part 0 holds the C ABI, the generic kernels and everything else, and only
+// DECLARES the hot launchers' instantiations; parts 1..6 each define those of one (layout, dtype).  Without PTG_PART this file is one
+// self-contained translation unit (hipcc -shared ptg_env.hip: the diagnostic builds, anybody's quick build).
+#define PTG_HOT_INST1(X, LAY, OUT, MOD, NZ)                                                                                              \
+    X template void ptg_hot::launch_step_hot<LAY, MOD, NZ, OUT>(ptg_env*, hipStream_t, const void*, int, OUT*, OUT*, uint8_t*);         \
+    X template void ptg_hot::launch_rollout_hot<LAY, MOD, NZ, OUT>(ptg_env*, hipStream_t, const void*, int, int, OUT*, OUT*, uint8_t*);
+#define PTG_HOT_INST(X, LAY, OUT)                                                                                                        \
+    PTG_HOT_INST1(X, LAY, OUT, true, NOISE_TAPE) PTG_HOT_INST1(X, LAY, OUT, false, NOISE_TAPE)                                           \
+    PTG_HOT_INST1(X, LAY, OUT, true, NOISE_RNG) PTG_HOT_INST1(X, LAY, OUT, false, NOISE_RNG)
+#define PTG_NOTHING
+#if defined(PTG_PART)
+#if PTG_PART == 0
+PTG_HOT_INST(extern, PTG_OBS_ROW_MAJOR, float) PTG_HOT_INST(extern, PTG_OBS_FEATURE_MAJOR, float) PTG_HOT_INST(extern, PTG_OBS_SB3_FLAT, float)
+PTG_HOT_INST(extern, PTG_OBS_SPLIT, float) PTG_HOT_INST(extern, PTG_OBS_ROW_MAJOR, double) PTG_HOT_INST(extern, PTG_OBS_FEATURE_MAJOR, double)
+#elif PTG_PART == 1
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_ROW_MAJOR, float)
+#elif PTG_PART == 2
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_FEATURE_MAJOR, float)
+#elif PTG_PART == 3
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_SB3_FLAT, float)
+#elif PTG_PART == 4
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_SPLIT, float)
+#elif PTG_PART == 5
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_ROW_MAJOR, double)
+#elif PTG_PART == 6
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_FEATURE_MAJOR, double)
+#else
+#error "PTG_PART must be 0..6"
+#endif
+#endif
+
+#if !defined(PTG_PART) || PTG_PART == 0      // ---- from here to the end of the file: part 0 only
+
+namespace {
+
+using ptg_hot::launch_step_hot;
+using ptg_hot::launch_rollout_hot;
 
 #define PTG_HOT_DISPATCH3(FN, LAY_, OUT_, ...)                                                           \
     do {                                                                                                \
@@ -3205,3 +3259,5 @@ int ptg_debug_window_record(ptg_env* h, int table_id, int start_row, double* out
 }
 
 }  // extern "C"
+
+#endif      // part 0
