@@ -231,27 +231,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        ev0.record()
+        if graph is not None:                      # (stream events only where no kernel-attached ones exist)
+            ev0.record()
         tA = time.perf_counter()
         if graph is not None:
             graph.replay()
+            ev1.record()
         else:
             run(W, K)
         tB = time.perf_counter()
-        ev1.record()
         r, l, _ = eng.finished_episodes()          # synchronises only if an episode can have ended; episodic-return reduction (one all-gather)
         tC = time.perf_counter()
-        with torch.cuda.stream(coll_stream):       # on a stream of its own: the collective runs beside the step kernels, not behind them
-            r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
+        if multi:
+            with torch.cuda.stream(coll_stream):   # on a stream of its own: the collective runs beside the step kernels, not behind them
+                r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
+        else:
+            r_all, l_all = r, l
         tD = time.perf_counter()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start    # this rank's time since the common start (barrier + synchronize); MAX over ranks below
         if os.environ.get("PTG_BENCH_DEBUG"):
-            print("timed region pieces us: ev0 %.0f run %.0f ev1+fin %.0f gather %.0f sync %.0f total %.0f" % ((tA - t_start) * 1e6, (tB - tA) * 1e6, (tC - tB) * 1e6, (tD - tC) * 1e6, (time.perf_counter() - tD) * 1e6, elapsed * 1e6), file=sys.stderr)
+            print("timed region pieces us: ev0 %.0f run %.0f fin %.0f gather %.0f sync %.0f total %.0f" % ((tA - t_start) * 1e6, (tB - tA) * 1e6, (tC - tB) * 1e6, (tD - tC) * 1e6, (time.perf_counter() - tD) * 1e6, elapsed * 1e6), file=sys.stderr)
         if multi:
             dist.barrier()
         eng.sync()
-        span_ms = ev0.elapsed_time(ev1)                       # stream events around the whole timed region (includes host launch latency)
+        span_ms = ev0.elapsed_time(ev1) if graph is not None else 0.0      # stream events around the replayed graph (host launch latency included)
         launch_us = None
         if graph is None:
             launch_us = eng.profile_read()
@@ -297,7 +301,8 @@ def main():
                        "(a replayed graph takes no per-kernel events); graph replay incl. boundaries: %.2f us per launch" % (res["span_ms"] * 1e3 / res["n_launch"]))
         else:                                                 # graph replay: stream events around the K back-to-back launches
             launches = res["n_launch"]
-            per_launch_s, how = res["span_ms"] * 1e-3 / launches, "HIP events around the replayed graph / launches (boundaries included)"
+            span_s = res["span_ms"] * 1e-3 if res["span_ms"] > 0 else res["elapsed"]      # (no events at all: the wall clock)
+            per_launch_s, how = span_s / launches, "HIP events around the replayed graph / launches (boundaries included)"
         bytes_per_launch = b_alg * n * steps / launches       # a rollout launch covers steps / launches steps (of <= 65 536 envs each)
         achieved = bytes_per_launch / per_launch_s / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

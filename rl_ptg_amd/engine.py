@@ -41,6 +41,7 @@ class HipEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); rl_ptg_amd has no CPU path")
         self.n = int(n_envs)
+        self._fin_buf = None
         self.device = torch.device("cuda", int(device))
         self.out_dtype = {"float32": torch.float32, "float64": torch.float64}[out_dtype]
         cfg = _lib.PtgConfig()
@@ -320,14 +321,15 @@ class HipEngine:
 
     def finished_episodes(self, cap=None):
         cap = max(2 * self.n, 1024) if cap is None else int(cap)          # the library's ring holds max(2 n, 1024) entries
-        r = np.zeros(cap)
-        l = np.zeros(cap, np.int32)
-        ids = np.zeros(cap, np.int32)
+        buf = self._fin_buf
+        if buf is None or buf[0].shape[0] < cap:                          # receive buffers kept across calls (2 MB at 65 536 envs)
+            buf = self._fin_buf = (np.zeros(cap), np.zeros(cap, np.int32), np.zeros(cap, np.int32))
+        r, l, ids = buf
         cnt = C.c_int(0)
         self._chk(self._L.ptg_finished_episodes(self._h, _dp(r), l.ctypes.data_as(C.POINTER(C.c_int32)),
                                                 ids.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(cnt)))
         n = cnt.value
-        return r[:n], l[:n], ids[:n]
+        return r[:n].copy(), l[:n].copy(), ids[:n].copy()
 
     # ------------------------------------------------------------------ VecNormalize(norm_obs=False) on the device
     def vn_init(self, gamma=0.99, epsilon=1e-8, clip_reward=10.0):
