@@ -59,9 +59,46 @@ __global__ void __launch_bounds__(256) k_chain(vf4* p, const vf4* q, size_t n16,
     for (size_t g = g0; g < n16; g += stride) __builtin_nontemporal_store(x, p + g);
 }
 
+// feature-major store pattern of the fused rollout: every wave owns 64 envs and writes, per step, F columns of 64 x `W` bytes at a
+// column stride of N x W bytes ([T][F][N] output).  rot = 0: every workgroup walks the columns in the same order (0, 1, 2, ...);
+// rot > 0: workgroup b starts at column (b x rot) % F.  Is the order what a power-of-two column stride trips over?
+template <typename V>
+__global__ void __launch_bounds__(256) k_fm(V* p, int N, int F, int T, int rot)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int q0 = rot ? (int)((blockIdx.x * (unsigned)rot) % (unsigned)F) : 0;
+    V v; __builtin_memset(&v, 0, sizeof v);
+    for (int t = 0; t < T; t++) {
+        V* row = p + (size_t)t * F * N + e;
+        int q = q0;
+        for (int i = 0; i < F; i++) {
+            __builtin_nontemporal_store(v, row + (size_t)q * N);
+            q = q + 1 == F ? 0 : q + 1;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// us per step of the pattern above (W = 4 or 8 bytes per env and column), T steps in one launch of N / 256 workgroups
+double fm_probe(void* buf, int N, int F, int T, int W, int rot)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0, 0);
+        if (W == 8) hipLaunchKernelGGL(k_fm<double>, dim3(N / 256), dim3(256), 0, 0, (double*)buf, N, F, T, rot);
+        else hipLaunchKernelGGL(k_fm<float>, dim3(N / 256), dim3(256), 0, 0, (float*)buf, N, F, T, rot);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)best * 1e3 / T;
+}
 
 double chain_probe(void* buf, void* buf2, size_t bytes, int kind, int n_launch)
 {
