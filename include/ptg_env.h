@@ -142,7 +142,9 @@ int ptg_set_market_assignment(ptg_env* env, const uint8_t* set_of_env_host);
  * DummyVecEnv when they terminate together (exclusive prefix sum over done flags).  n = 0: validation/test env. */
 int ptg_set_episode_plan(ptg_env* env, const double* eps_ind_host, int n, int64_t first_ptr, int64_t stride);
 /* Normal draws consumed at state changes (:584-585,598-599,620-621): the c-th draw of env e is tape[e*len + c mod len].
- * Host tape (e.g. numpy Generator.normal(0, noise) per env for bit parity with the reference) ... */
+ * Host tape (e.g. numpy Generator.normal(0, noise) per env for bit parity with the reference), env-major [n_envs][per_env_len] as
+ * written here; the library keeps it draw-major on the device (ptg_set / get_noise_tape transpose, a temporary device buffer of the
+ * tape's size while they run) ... */
 int ptg_set_noise_tape(ptg_env* env, const double* tape_host, int per_env_len);
 /* ... or the device's counter-based generator: the c-th draw of the env with GLOBAL index g is
  *   noise(seed, g, c) = cfg.noise * BoxMuller(u1, u2),  (u1, u2) from three rounds of the 32-bit integer finaliser "lowbias32"

@@ -92,7 +92,7 @@ struct DevParams {
     const int2* tabmeta;                   // [17] {rows, record base}
     const int* argidx;                     // [6][nT]
     const double* Tvals;                   // [nT]
-    const double* tape;                    // [N][tape_len]
+    const double* tape;                    // [tape_len][N] (draw-major, see k_fill_noise)
     const int* eps_ind;                    // [E]
     const double2* sincos;                 // [eps_sim_steps + 1]
     const float2* sincos32;
@@ -216,11 +216,30 @@ __device__ __forceinline__ double noise_draw(unsigned long long seed, long long 
     return sigma * (double)(r * __cosf(6.28318530717958647692f * u2));
 }
 
+// The device tape is draw-major, [L][N]: lane e of a wave reads draw (noise_count[e] % L) of env e, and envs that consumed the same
+// number of draws -- most of a synchronised batch -- then share cache lines (env-major rows of L doubles put every lane on a line
+// of its own, 8 KiB apart at L = 1024).  The C ABI keeps the env-major [N][L] host layout (ptg_set / get_noise_tape transpose).
 __global__ void k_fill_noise(double* __restrict__ tape, int N, int L, unsigned long long seed, long long env_offset, double sigma)
 {
     long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)N * L) return;
-    tape[g] = noise_draw(seed, g / L + env_offset, (unsigned)(g % L), sigma);
+    tape[g] = noise_draw(seed, g % N + env_offset, (unsigned)(g / N), sigma);
+}
+
+// in [rows][cols] -> out [cols][rows], 32 x 32 tiles through LDS (block 32 x 8)
+__global__ void k_transpose(const double* __restrict__ in, double* __restrict__ out, int rows, int cols)
+{
+    __shared__ double tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ the env step
@@ -302,7 +321,7 @@ __device__ __forceinline__ int step_ints(const DevParams& P, const int2* tabmeta
     const int idx = lut.get(dest, tkey);
     double z = 0.0;
     if (noisy) {
-        if (P.tape_len > 0) z = P.tape[(size_t)e * P.tape_len + ((unsigned)R.b.nctr % (unsigned)P.tape_len)];
+        if (P.tape_len > 0) z = P.tape[(size_t)((unsigned)R.b.nctr % (unsigned)P.tape_len) * P.N + e];
         else if (P.noise_inline) z = noise_draw(P.noise_seed, P.env_offset + e, (unsigned)R.b.nctr, P.noise_sigma);
         R.b.nctr += 1;
     }
@@ -898,9 +917,10 @@ __device__ __forceinline__ const double* series(const HotParams& P, const double
 enum { NOISE_NONE = 0, NOISE_TAPE = 1, NOISE_RNG = 2 };
 
 // Integer state machine (:339-440, :525-757), branch-free.  Returns the record index.
-template <int NOISE>
+// ZPRE (tape mode, the rollout's producers): the env's next tape entry was fetched one step ahead and arrives in z_pre
+template <int NOISE, bool ZPRE = false>
 __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
-                                        HotRegs& R, int act, int e, bool& changed)
+                                        HotRegs& R, int act, int e, bool& changed, double z_pre = 0.0)
 {
     const unsigned f = R.flags;
     const int s = f & 7, sb = (f >> 4) & 1, su = (f >> 5) & 1, pp = (f >> 6) & 7, fq = (f >> 9) & 7;
@@ -924,7 +944,10 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
     int i_noisy = 0;
     if (__ballot(noisy)) {                           // :584-585 int(max(idx + normal(0, noise), 0))
         double z = 0.0;
-        if (NOISE == NOISE_TAPE) { if (noisy) z = P.tape[(size_t)e * P.tape_len + ((unsigned)R.nctr % (unsigned)P.tape_len)]; }
+        if (NOISE == NOISE_TAPE) {
+            if (ZPRE) z = z_pre;
+            else if (noisy) z = P.tape[(size_t)((unsigned)R.nctr % (unsigned)P.tape_len) * P.N + e];
+        }
         else if (NOISE == NOISE_RNG) z = noise_draw(P.noise_seed, P.env_offset + e, (unsigned)R.nctr, P.noise_sigma);
         R.nctr += noisy ? 1 : 0;
         double x = (double)idx + z;
@@ -1545,6 +1568,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         return s_mkt[((q < 13 ? 0 : 13) + r) * NP + lx];
     };
     unsigned tk = 0;                                        // producer: key of the window entered by the previous step (in flight)
+    double z_next = 0.0;                                    // producer, tape mode: the env's next tape entry (in flight)
     rec_t recA, recB; unsigned wA = 0, wB = 0;              // consumer: records in flight (ping-pong: no copies of pending loads)
     if (!producer) {
         setc = P.setc[mset];
@@ -1566,8 +1590,15 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         const int code = s_act[it * NP + lx];
         const int act = (code == 7) ? (int)((R.flags >> 12) & 7) : code;
         bool changed;
-        const int ridx = hot_ints<NOISE>(P, L, lut, LDSLUT, R, act, e, changed);
+        const int nctr0 = R.nctr;
+        const int ridx = hot_ints<NOISE, NOISE == NOISE_TAPE>(P, L, lut, LDSLUT, R, act, e, changed, z_next);
         tk = ld_off<unsigned short>(rkey, (unsigned)ridx * 2u);
+        // tape mode: the draw the env will consume next is fetched as soon as the previous one is used up -- steps ahead of its use,
+        // as a rule (a load inside the step that needs it is a second dependent round trip: 2.25 us per step against 1.5)
+        if (NOISE == NOISE_TAPE) {
+            const bool used = R.nctr != nctr0;
+            if (__ballot(used)) { if (used) z_next = P.tape[(size_t)((unsigned)R.nctr % (unsigned)P.tape_len) * P.N + e]; }
+        }
         slot[it & 1].w[lx] = (unsigned)ridx | ((R.flags & 7u) << 24) | (changed ? (1u << 27) : 0u) |
                              (((R.flags >> 12) & 7u) << 28) | (((R.flags >> 3) & 1u) << 31);       // + action, hot / cold: the info rows' fields
     };
@@ -1666,6 +1697,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     // backend's vmcnt bookkeeping sees only that role's loads and stores (a shared loop with the roles as exec-masked regions
     // made it drain the whole queue at the top of every consumer iteration).
     if (producer) {
+        if (NOISE == NOISE_TAPE) z_next = P.tape[(size_t)((unsigned)R.nctr % (unsigned)P.tape_len) * P.N + e];
         for (int it = 0; it < T; it++) { produce(it); handoff(); if (it == 0) PTG_STAMP(4); if (it == 1) PTG_STAMP(5); }
         PTG_STAMP(6);
         handoff();
@@ -2649,8 +2681,18 @@ int ptg_set_noise_tape(ptg_env* h, const double* tape_host, int per_env_len)
     int rc = set_tape_len(h, per_env_len);
     if (rc) return rc;
     h->P.noise_inline = 0;
-    if (per_env_len > 0)
-        HIP_TRY(h, hipMemcpy(h->d_tape, tape_host, sizeof(double) * (size_t)h->n * per_env_len, hipMemcpyHostToDevice));
+    if (per_env_len > 0) {                                     // env-major host rows -> the draw-major device tape
+        double* tmp = nullptr;
+        const size_t bytes = sizeof(double) * (size_t)h->n * per_env_len;
+        HIP_TRY(h, hipMalloc((void**)&tmp, bytes));
+        hipError_t e = hipMemcpy(tmp, tape_host, bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_transpose, dim3((per_env_len + 31) / 32, (h->n + 31) / 32), dim3(32, 8), 0, 0, tmp, h->d_tape, h->n, per_env_len);
+            e = hipDeviceSynchronize();
+        }
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return set_err(h, PTG_E_HIP, "noise tape upload failed: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(k_zero_noise_count, dim3(grid_for(h->n, 256)), dim3(256), 0, 0, h->P);
     if ((rc = launch_check(h, "k_zero_noise_count"))) return rc;
     HIP_TRY(h, hipDeviceSynchronize());
@@ -2699,7 +2741,14 @@ int ptg_get_noise_tape(ptg_env* h, double* tape_host)
     if (h->tape_len <= 0) return set_err(h, PTG_E_INVALID, "no noise tape set");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(tape_host, h->d_tape, sizeof(double) * (size_t)h->n * h->tape_len, hipMemcpyDeviceToHost));
+    double* tmp = nullptr;                                     // the draw-major device tape -> env-major host rows
+    const size_t bytes = sizeof(double) * (size_t)h->n * h->tape_len;
+    HIP_TRY(h, hipMalloc((void**)&tmp, bytes));
+    hipLaunchKernelGGL(k_transpose, dim3((h->n + 31) / 32, (h->tape_len + 31) / 32), dim3(32, 8), 0, 0, (const double*)h->d_tape, tmp, h->tape_len, h->n);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(tape_host, tmp, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return set_err(h, PTG_E_HIP, "noise tape download failed: %s", hipGetErrorString(e));
     return 0;
 }
 
