@@ -91,3 +91,44 @@ def test_batches_wider_than_one_launch(n):
         assert np.array_equal(a, b), (what, n)
     for f, v in ref[3].items():
         assert np.array_equal(hot[3][f], v), (f, n)
+
+
+def test_rollout_captured_into_a_graph_and_replayed_once():
+    """ptg_rollout inside a stream capture (torch.cuda.graph): nothing runs at capture time (the table refresher is skipped while
+    capturing), one replay produces what the eager call produces on a twin engine, and the host-side step count stays in step."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=8)
+    n, Tg = 4096, 24
+    dev = torch.device("cuda", 0)
+    acts = torch.from_numpy(np.random.default_rng(5).integers(0, 5, (2 * Tg, n)).astype(np.int32)).to(dev)
+    outs = []
+    for mode in ("eager", "graph"):
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="row")
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        eng.set_noise_rng(9)
+        eng.reset()
+        obs = torch.zeros((Tg, n, eng.obs_dim), device=dev); rew = torch.zeros((Tg, n), device=dev)
+        done = torch.zeros((Tg, n), dtype=torch.uint8, device=dev)
+        if mode == "eager":
+            eng.rollout(acts[:Tg], obs, rew, done)
+        else:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    eng.rollout(acts[:Tg], obs, rew, done)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            assert float(obs.abs().sum()) == 0.0               # captured, not run
+            g.replay()
+        eng.sync()
+        first = (obs.cpu().numpy().copy(), rew.cpu().numpy().copy())
+        eng.rollout(acts[Tg:], obs, rew, done)                  # eager continuation: the handle's step count matches the device state
+        eng.sync()
+        outs.append(first + (obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), eng.get_state("k"), eng.get_state("cum_rew")))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
