@@ -132,3 +132,52 @@ def test_rollout_captured_into_a_graph_and_replayed_once():
         eng.close()
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+def test_two_handles_on_two_streams_at_once():
+    """Two independent handles driven from two streams at the same time (rollouts and per-step launches interleaved): each gets what
+    it gets alone -- no state shared between handles (error words, refresher stream, profiling lists are per handle)."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    dev = torch.device("cuda", 0)
+    specs = [synthetic_spec(scenario=1, operation="OP1", eps_len_d=8)[0], synthetic_spec(scenario=3, operation="OP2", eps_len_d=8)[0]]
+    n, Tn = 8192, 40
+    rng = np.random.default_rng(11)
+    acts = [torch.from_numpy(rng.integers(0, 5, (Tn, n)).astype(np.int32)).to(dev) for _ in range(2)]
+
+    def make(i):
+        eng = HipEngine(specs[i].consts, specs[i].tables, specs[i].markets, n, device=0, out_dtype=("float32", "float64")[i], obs_layout="row")
+        eng.set_episode_plan(specs[i].eps_ind, n, n)
+        eng.set_noise_rng(20 + i)
+        eng.reset()
+        return eng
+
+    def drive(eng, a):                                       # 16 fused steps, 8 single steps, 16 fused steps
+        o1, r1, _ = eng.rollout(a[:16])
+        for t in range(16, 24):
+            eng.step(a[t], want_final=False)
+        o2, r2, _ = eng.rollout(a[24:])
+        return o1, r1, o2, r2
+
+    alone = []
+    for i in range(2):
+        eng = make(i)
+        res = drive(eng, acts[i])
+        eng.sync()
+        alone.append([x.cpu().numpy().copy() for x in res] + [eng.get_state("cum_rew")])
+        eng.close()
+    engs = [make(0), make(1)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    res = [None, None]
+    for i in (0, 1):
+        with torch.cuda.stream(streams[i]):
+            res[i] = drive(engs[i], acts[i])
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        engs[i].sync()
+        got = [x.cpu().numpy() for x in res[i]] + [engs[i].get_state("cum_rew")]
+        for a, b in zip(got, alone[i]):
+            assert np.array_equal(a, b), i
+        engs[i].close()
