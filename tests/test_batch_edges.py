@@ -181,3 +181,48 @@ def test_two_handles_on_two_streams_at_once():
         for a, b in zip(got, alone[i]):
             assert np.array_equal(a, b), i
         engs[i].close()
+
+
+def test_api_misuse_returns_error_codes():
+    """Call-order and argument mistakes come back as PTG_E_INVALID (-1) with a message, never as a crash or a silent success:
+    stepping before the first reset, null buffers, an action kind that contradicts cfg.action_type, zero steps, an unknown state
+    field, asking for a tape that was never set; and the handle keeps working afterwards."""
+    import ctypes as C
+    import torch
+    from rl_ptg_amd import _lib
+    from rl_ptg_amd.engine import HipEngine, PtgError
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=8)
+    L = _lib.lib()
+    n = 300
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype="float32", obs_layout="row")
+    eng.set_episode_plan(spec.eps_ind, n, n)
+    h = eng._h
+    dev = torch.device("cuda", 0)
+    a_i = torch.zeros(n, dtype=torch.int32, device=dev); a_f = torch.zeros(n, dtype=torch.float32, device=dev)
+    obs = torch.zeros((4, n, eng.obs_dim), device=dev); rew = torch.zeros((4, n), device=dev); done = torch.zeros((4, n), dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    E = -1
+    assert L.ptg_step(h, p(a_i), _lib.ACT_I32, p(obs), p(rew), p(done), None, None, None) == E          # not reset yet
+    assert b"reset" in L.ptg_last_error(h)
+    assert L.ptg_rollout(h, p(a_i), _lib.ACT_I32, 1, p(obs), p(rew), p(done), None) == E
+    eng.reset()
+    assert L.ptg_step(h, None, _lib.ACT_I32, p(obs), p(rew), p(done), None, None, None) == E             # null actions
+    assert L.ptg_step(h, p(a_i), _lib.ACT_I32, None, p(rew), p(done), None, None, None) == E             # null observations
+    assert L.ptg_step(h, p(a_f), _lib.ACT_F32, p(obs), p(rew), p(done), None, None, None) == E           # float actions, discrete env
+    assert L.ptg_step(h, p(a_i), 7, p(obs), p(rew), p(done), None, None, None) == E                      # no such action kind
+    assert L.ptg_rollout(h, p(a_i), _lib.ACT_I32, 0, p(obs), p(rew), p(done), None) == E                 # zero steps
+    assert L.ptg_rollout_launches(h, 0) < 0
+    buf = (C.c_double * n)()
+    assert L.ptg_get_state(h, 77, buf) == E and L.ptg_set_state(h, 77, buf) == E                         # unknown field
+    assert L.ptg_get_noise_tape(h, buf) == E                                                             # no tape set
+    assert L.ptg_set_noise_tape(h, None, 8) == E
+    assert L.ptg_finished_episodes(h, None, None, None, 4, None) == E
+    assert L.ptg_step(None, p(a_i), _lib.ACT_I32, p(obs), p(rew), p(done), None, None, None) == E        # null handle
+    with pytest.raises(PtgError):
+        eng._chk(L.ptg_get_state(h, 78, buf))                                                          # the Python binding raises on a code
+    # ... and the handle is still good
+    o, r, d = eng.rollout(np.full((4, n), 2, np.int32), obs, rew, done)
+    eng.sync()
+    assert np.isfinite(o.cpu().numpy()).all() and int(eng.get_state("k")[0]) == 4
+    eng.close()
