@@ -3,8 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, RCCL).  Weak scaling: every rank owns --envs (default 65 536) envs; no per-step communication;
-one all-gather of finished-episode returns closes the timed region.
+(one rank per GPU, RCCL); started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it spawns the N ranks itself,
+before anything in the parent touches a GPU.  Weak scaling: every rank owns --envs (default 65 536) envs; no per-step
+communication.  The one collective of the path -- the all-gather of finished-episode returns -- is issued only when the timed
+window contains an episode boundary ("at episode boundaries only"; the host knows the step on which a synchronised
+batch's episodes end, ptg_steps_to_episode_end); its cost is reported by the `episode_boundary` leg, which times a window that
+does contain one.
 
 A "step" is one vector step of the hot path over the whole batch (N_envs env-steps per rank).  Headline: `ptg_rollout`
 (K steps fused into as few launches as fit) writing ROW-MAJOR [N, F] float32 observations -- the layout of the boundary
@@ -14,13 +18,14 @@ flags are resident in HBM; nothing crosses PCIe inside the timed region.
 Workload: BASELINE.json configs[2] -- N = 65 536 envs, BS1/OP1, synthetic 38-day trace (32-day episodes), 'mod'
 features, discrete sticky actions, in-kernel counter RNG for the state-change noise.
 
-Timing.  `value` is wall clock over the K timed steps: barrier + synchronize, start, K steps + the finished-episode all-gather (on a
-stream of its own, beside the kernels), synchronize, stop, barrier; N > 1: the MAX of that over the ranks.  `roofline` uses the
-kernel's own duration: every timed launch carries a HIP event pair stamped at the kernel's begin and end
-(ptg_profile, hipExtLaunchKernelGGL) -- what rocprofv3 --kernel-trace reports for the dispatch -- because an event
-recorded from Python on an idle stream also counts the host's launch latency (20 us of the 55 us round 1 reported
-for 20 steps).  `roofline` = the K timed steps exactly as the driver asked for them (few steps right after a reset:
-launch prologue and drain are not amortised); `steady_state` = a 400-step launch run after the timed region.
+Timing.  `value` is wall clock over the K timed steps: barrier + synchronize, start, K steps (+ the finished-episode all-gather when
+the window holds an episode boundary), synchronize, stop, barrier; N > 1: the MAX of that over the ranks.  `roofline` uses device
+time: every timed launch carries a HIP event pair stamped at the kernel's begin and end (ptg_profile, hipExtLaunchKernelGGL) -- what
+rocprofv3 --kernel-trace reports for the dispatch -- because an event recorded from Python on an idle stream also counts the host's
+launch latency.  The interval is the UNION of the rollout kernel and the table refresher that may run beside it (ptg_profile_read_ex:
+first start to last end; `refresh_us` = the helper's own duration, 0 when the launch needed none -- the pass at the head of a launch is
+part of the rollout kernel itself since round 3).  `roofline` = the K timed steps exactly as the driver asked for them (few steps
+right after a reset: launch prologue and drain are not amortised); `steady_state` = a 400-step launch run after the timed region.
 """
 import argparse
 import json
@@ -108,6 +113,34 @@ def cpu_baseline(spec, n_envs=131072, n_steps=105, seed=7):
                                  }}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks as fresh child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and exit with the worst of their codes.  The parent makes no
+    HIP call (torch.cuda.device_count() does not initialise the GPU on this image)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("PTG_BENCH_BACKEND", "nccl")
+    try:
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:
+        have = 0
+    if backend == "nccl" and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; RCCL needs one GPU per rank "
+                         "(PTG_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks per GPU)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +160,12 @@ def main():
     ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
     ap.add_argument("--noise", choices=["rng", "tape"], default="rng", help="in-kernel counter RNG or a device-filled tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary-leg", dest="boundary_leg", action="store_false",
+                    help="skip the episode_boundary leg (a window that contains the episode end + the finished-episode all-gather)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)                     # no launcher: this process becomes the launcher (and never touches a GPU)
 
     import torch
     import torch.distributed as dist
@@ -139,9 +177,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the env step has no CPU path")
     backend = os.environ.get("PTG_BENCH_BACKEND", "nccl")       # "gloo": rehearse the N > 1 path with several ranks on one GPU
@@ -225,6 +262,18 @@ def main():
             torch.cuda.current_stream(device).wait_stream(side)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_launch = eng.rollout_launches(K) if path == "rollout" else K        # kernel launches inside the timed region
+        # Does an episode end inside the timed window?  Host-known for a synchronised batch; all ranks must take the same branch (a
+        # collective sits behind it), so the answer is agreed on OUTSIDE the clock.  Without a boundary nothing can have finished:
+        # no query, no collective (the all-gather belongs to episode boundaries, not to the step path).
+        s_end = eng.steps_to_episode_end()
+        boundary = s_end == 0 or s_end <= K
+        if multi:
+            flag = torch.tensor([1.0 if boundary else 0.0], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            boundary = bool(flag.item() > 0)
+        # the slices the timed calls take are made before the clock starts (harness work, not the env's)
+        if path == "rollout":
+            timed_args = (actions[W:W + K], bufs[0][:K], bufs[1][:K], bufs[2][:K])
         if graph is None:
             eng.profile(True)                                 # kernel-attached begin / end events on every timed launch
         if multi:
@@ -237,38 +286,42 @@ def main():
         if graph is not None:
             graph.replay()
             ev1.record()
+        elif path == "rollout":
+            eng.rollout(*timed_args)
         else:
             run(W, K)
         tB = time.perf_counter()
-        r, l, _ = eng.finished_episodes()          # synchronises only if an episode can have ended; episodic-return reduction (one all-gather)
-        tC = time.perf_counter()
-        if multi:
-            with torch.cuda.stream(coll_stream):   # on a stream of its own: the collective runs beside the step kernels, not behind them
-                r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
-        else:
-            r_all, l_all = r, l
+        r_all, l_all = (), ()
+        if boundary:
+            r, l, _ = eng.finished_episodes()      # episodic-return reduction: one all-gather over the ranks
+            if multi:
+                with torch.cuda.stream(coll_stream):   # on a stream of its own: the collective runs beside the step kernels, not behind them
+                    r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device)
+            else:
+                r_all, l_all = r, l
         tD = time.perf_counter()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start    # this rank's time since the common start (barrier + synchronize); MAX over ranks below
         if os.environ.get("PTG_BENCH_DEBUG"):
-            print("timed region pieces us: ev0 %.0f run %.0f fin %.0f gather %.0f sync %.0f total %.0f" % ((tA - t_start) * 1e6, (tB - tA) * 1e6, (tC - tB) * 1e6, (tD - tC) * 1e6, (time.perf_counter() - tD) * 1e6, elapsed * 1e6), file=sys.stderr)
+            print("timed region pieces us: ev0 %.0f run %.0f fin+gather %.0f sync %.0f total %.0f" % ((tA - t_start) * 1e6, (tB - tA) * 1e6, (tD - tB) * 1e6, (time.perf_counter() - tD) * 1e6, elapsed * 1e6), file=sys.stderr)
         if multi:
             dist.barrier()
         eng.sync()
         span_ms = ev0.elapsed_time(ev1) if graph is not None else 0.0      # stream events around the replayed graph (host launch latency included)
-        launch_us = None
+        launch_us = kernel_us = helper_us = None
         if graph is None:
-            launch_us = eng.profile_read()
+            kernel_us, helper_us, launch_us = eng.profile_read_ex()      # launch_us: the union of each launch and its helper
             eng.profile(False)
         else:
             # a replayed graph takes no kernel-attached events: the same K steps are launched once more, eagerly and OUTSIDE the timed
             # region, for the kernel's own duration (what rocprofv3 --kernel-trace reports per dispatch); `value` stays the graph replay
             eng.profile(True)
             run(W + K, K)
-            launch_us = eng.profile_read()
+            kernel_us, helper_us, launch_us = eng.profile_read_ex()
             eng.profile(False)
-        res = {"elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "n_launch": n_launch, "n_fin": len(r_all), "F": F, "steady": None,
-               "rerun": graph is not None}
+        res = {"elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "kernel_us": kernel_us, "helper_us": helper_us, "n_launch": n_launch,
+               "n_fin": len(r_all), "F": F, "steady": None, "rerun": graph is not None, "boundary": boundary, "steps_to_episode_end": s_end,
+               "elapsed_rank": elapsed, "device_us_rank": float(np.sum(launch_us)) if launch_us is not None else span_ms * 1e3}
         if extra:                                             # steady state: two more 400-step launches, the second one counted
             eng.profile(True)
             for q in range(2):
@@ -279,15 +332,19 @@ def main():
             per = len(us) // 2
             res["steady"] = {"steps": STEADY_T, "launch_us": [float(u) for u in us[per:]]}
         if multi:
-            dev_sum = float(np.sum(launch_us)) if launch_us is not None else span_ms * 1e3
-            tmax = torch.tensor([elapsed, dev_sum], dtype=torch.float64, device=coll_device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            res["elapsed"] = float(tmax[0])
+            # every rank's (wall, device time) to every rank: the MAX is the job's time; the list shows whether a rank lags
+            mine = torch.tensor([float(rank), elapsed, res["device_us_rank"]], dtype=torch.float64, device=coll_device)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            every = torch.stack(every).cpu().numpy()
+            res["per_rank"] = [{"rank": int(a[0]), "wall_us": float(a[1]) * 1e6, "device_us": float(a[2])} for a in every]
+            res["ranks_seen"] = int(len(set(int(a[0]) for a in every)))
+            res["elapsed"] = float(every[:, 1].max())
+            dev_sum, dev_max = res["device_us_rank"], float(every[:, 2].max())
             if launch_us is not None and len(launch_us):
-                launch_us = launch_us * (float(tmax[1]) / max(dev_sum, 1e-9))      # slowest rank's device time, same launch count
-                res["launch_us"] = launch_us
+                res["launch_us"] = launch_us * (dev_max / max(dev_sum, 1e-9))      # slowest rank's device time, same launch count
             else:
-                res["span_ms"] = float(tmax[1]) * 1e-3
+                res["span_ms"] = dev_max * 1e-3
         eng.close()
         return res
 
@@ -295,7 +352,8 @@ def main():
         b_alg = algorithmic_bytes_per_env_step(res["F"], out_bytes, path)
         if res["launch_us"] is not None and len(res["launch_us"]):
             per_launch_s = float(np.mean(res["launch_us"])) * 1e-6
-            launches, how = len(res["launch_us"]), "HIP events attached to each timed kernel launch (ptg_profile)"
+            launches, how = len(res["launch_us"]), ("HIP events attached to each timed kernel launch and to the table refresher beside it, if any "
+                                                    "(ptg_profile_read_ex): first start to last end")
             if res.get("rerun"):
                 how = ("HIP events attached to each kernel launch of an eager re-run of the same K steps right after the timed graph replay "
                        "(a replayed graph takes no per-kernel events); graph replay incl. boundaries: %.2f us per launch" % (res["span_ms"] * 1e3 / res["n_launch"]))
@@ -305,10 +363,14 @@ def main():
             per_launch_s, how = span_s / launches, "HIP events around the replayed graph / launches (boundaries included)"
         bytes_per_launch = b_alg * n * steps / launches       # a rollout launch covers steps / launches steps (of <= 65 536 envs each)
         achieved = bytes_per_launch / per_launch_s / 1e9
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None, "kernel": "k_step_hot" if path == "step" else "k_rollout_pc",
                 "algorithmic_bytes_per_env_step": b_alg, "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
                 "steps_per_launch": steps / launches, "timing": how}
+        if res.get("kernel_us") is not None and len(res["kernel_us"]):
+            roof["kernel_only_us"] = float(np.mean(res["kernel_us"]))      # the rollout / step kernel's own duration
+            roof["refresh_us"] = float(np.mean(res["helper_us"]))          # k_refresh beside it (0: the launch needed none; the head pass is inside the kernel)
+        return roof
 
     out_bytes = 4 if args.out_dtype == "float32" else 8
     tj = {}
@@ -338,7 +400,11 @@ def main():
         name = (f"ptg_rollout, K steps fused ({res['n_launch']} kernel launch(es): <= 65536 envs x <= ~400 steps each)" if path == "rollout" else
                 f"ptg_step, one launch per vector step ({'K launches replayed as one hipGraph' if args.launch == 'graph' else 'eager launches'})")
         d = {"path": name, "obs_layout": layout, "obs_dtype": dtype, "value": n_total * K / res["elapsed"], "unit": "env-steps/s",
-             "ms_per_step": res["elapsed"] * 1e3 / K, "roofline": roof}
+             "ms_per_step": res["elapsed"] * 1e3 / K, "roofline": roof, "episode_boundary_in_window": bool(res["boundary"]),
+             "steps_to_episode_end": res["steps_to_episode_end"]}
+        if "per_rank" in res:
+            d["per_rank"] = res["per_rank"]
+            d["rccl_ranks_seen" if backend == "nccl" else "ranks_seen"] = res["ranks_seen"]
         if res["steady"]:
             us = res["steady"]["launch_us"]
             b_alg = roof["algorithmic_bytes_per_env_step"]
@@ -347,6 +413,50 @@ def main():
                                  "us_per_step": t * 1e6 / STEADY_T, "achieved": b_alg * n * STEADY_T / t / 1e9, "unit": "GB/s",
                                  "frac": b_alg * n * STEADY_T / t / 1e9 / HBM_PEAK_GBPS, "env_steps_per_s_device": n * STEADY_T / t}
         return d, res
+
+    def boundary_leg(B=20, chunk=100):
+        """The window the step path's timed region never holds: the last B steps of an episode INCLUDING the terminating one (generic
+        kernel: termination, auto-reset over the episode plan, finished-episode compaction), the finished-episode query and the
+        all-gather of the episodic returns over the ranks -- the one collective of the path, at the one place it belongs."""
+        torch.cuda.empty_cache()
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
+        eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
+        eng.set_global_env_offset(first_ptr - n_total)
+        eng.set_noise_rng(seed=20250614)
+        F = eng.obs_dim
+        acts = sticky_actions_device(chunk + B, n, seed=4321 + rank, device=device, p_switch=args.p_switch)
+        oshape = (chunk, F, n) if args.obs_layout == "feature" else (chunk, n, F)
+        bufs = (torch.zeros(oshape, dtype=eng.out_dtype, device=device), torch.zeros((chunk, n), dtype=eng.out_dtype, device=device),
+                torch.zeros((chunk, n), dtype=torch.uint8, device=device))
+        eng.reset()
+        pre = eng.steps_to_episode_end() - B
+        t = 0
+        while t < pre:                                        # (the same action rows again and again: only the position matters here)
+            c = min(chunk, pre - t)
+            eng.rollout(acts[:c], bufs[0][:c], bufs[1][:c], bufs[2][:c])
+            t += c
+        eng.sync()
+        timed_args = (acts[chunk:chunk + B], bufs[0][:B], bufs[1][:B], bufs[2][:B])
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.rollout(*timed_args)
+        t1 = time.perf_counter()
+        r, l, _ = eng.finished_episodes()
+        t2 = time.perf_counter()
+        r_all, l_all = ptg_dist.all_gather_finished(r, l, device=coll_device) if multi else (r, l)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if multi:
+            dist.barrier()
+        out = {"what": f"the last {B} steps of the episode incl. the terminating step + finished-episode query + all-gather of the returns over {world} rank(s)",
+               "steps": B, "wall_us": (t3 - t0) * 1e6, "enqueue_us": (t1 - t0) * 1e6, "finished_query_us": (t2 - t1) * 1e6, "all_gather_us": (t3 - t2) * 1e6,
+               "finished_local": int(len(r)), "finished_gathered": int(len(r_all)), "dropped": eng.finished_dropped(),
+               "mean_return": float(np.mean(r_all)) if len(r_all) else None, "mean_length": float(np.mean(l_all)) if len(l_all) else None,
+               "env_steps_per_s_in_window": n * B / (t3 - t0)}
+        eng.close()
+        return out
 
     head, res = leg(args.path, args.obs_layout, args.out_dtype, steady=args.steady and n <= 131072)     # (400-step buffers: 3.7 GB per 65 536 envs)
     also = {}
@@ -358,6 +468,12 @@ def main():
         if args.out_dtype == "float32":                   # the reference's declared dtype (env/ptg_gym_env.py:166-202): float64 observations / rewards
             also["rollout_" + args.obs_layout + "_float64"] = leg("rollout", args.obs_layout, "float64")[0]
 
+    boundary = None
+    if args.boundary_leg:
+        try:
+            boundary = boundary_leg()
+        except Exception as ex:                               # reported, never fatal for the headline
+            boundary = {"error": repr(ex)}
     if rank == 0:
         ppath = os.path.join(ROOT, "profiles", "hbm_probe_latest.json")
         if os.path.exists(ppath):                     # stream rates measured on this chip next to the vendor peak
@@ -381,10 +497,15 @@ def main():
             "roofline": head["roofline"],
             "finished_episodes_gathered": int(res["n_fin"]),
         }
+        for key in ("episode_boundary_in_window", "steps_to_episode_end", "per_rank", "rccl_ranks_seen", "ranks_seen"):
+            if key in head:
+                line[key] = head[key]
         if "steady_state" in head:
             line["steady_state"] = head["steady_state"]
         if also:
             line["also"] = also
+        if boundary is not None:
+            line["episode_boundary"] = boundary
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define PTG_ABI_VERSION 3   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series */
+#define PTG_ABI_VERSION 4   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series;
+                             * 4: + ptg_profile_read_ex, ptg_finished_dropped, ptg_host_buffers_changed, ptg_steps_to_episode_end */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -91,7 +92,7 @@ typedef struct ptg_config {
     double state_change_penalty;        /* :332 */
     double t_cat_initial;               /* 16 in the reference (:117) */
     int32_t out_dtype;                  /* PTG_OUT_F32 | PTG_OUT_F64 */
-    int32_t obs_layout;                 /* PTG_OBS_ROW_MAJOR | PTG_OBS_FEATURE_MAJOR | PTG_OBS_SB3_FLAT */
+    int32_t obs_layout;                 /* PTG_OBS_ROW_MAJOR | PTG_OBS_FEATURE_MAJOR | PTG_OBS_SB3_FLAT | PTG_OBS_SPLIT */
 } ptg_config;
 
 /* The 17 process tables (src/rl_utils.py:46-67): row-major [rows][7] = t, T_cat, n_h2, n_ch4, n_h2_res, m_h2o, P_el */
@@ -197,6 +198,10 @@ int ptg_rollout_info(ptg_env* env, const void* actions_dev, int action_kind, int
 int ptg_host_layout(const ptg_env* env, size_t* off_rew, size_t* off_done, size_t* total);
 int ptg_step_host(ptg_env* env, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
                   int* n_done, void* stream);
+/* ptg_step_host remembers, per buffer ADDRESS (the last 8), whether the buffer is device-mapped pinned memory.  A buffer must stay
+ * allocated / registered for as long as it is passed to ptg_step_host; a caller that frees one and later passes memory of another
+ * kind at the same address calls this first (forgets the classifications). */
+int ptg_host_buffers_changed(ptg_env* env);
 /* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
  * per-launch timing); negative PTG_E_* on a bad argument. */
 int ptg_rollout_launches(ptg_env* env, int n_steps);
@@ -208,6 +213,12 @@ int ptg_rollout_launches(ptg_env* env, int n_steps);
  * (count = min(launches, cap)) and clears the collection.  Launches being captured into a hipGraph must not be profiled. */
 int ptg_profile(ptg_env* env, int enable);
 int ptg_profile_read(ptg_env* env, double* us_host, int cap, int* count);
+/* ptg_profile_read with the launches' helper kernel accounted for.  A rollout launch may run a table refresher beside it (k_refresh on
+ * a stream forked from the caller's: the rolling passes of a long launch right after a synchronised reset; the pass at the head of a
+ * launch is part of the rollout kernel itself).  Per recorded launch: us_host = the kernel's own duration, helper_us_host (nullable)
+ * = its helper's duration or 0, span_us_host (nullable) = the length of the UNION of the two intervals, first start to last end --
+ * the figure bench.py's roofline uses. */
+int ptg_profile_read_ex(ptg_env* env, double* us_host, double* helper_us_host, double* span_us_host, int cap, int* count);
 /* hipStreamSynchronize(stream) + report an error a kernel flagged (PTG_E_ACTION / PTG_E_RANGE). */
 int ptg_sync(ptg_env* env, void* stream);
 
@@ -227,6 +238,14 @@ int ptg_set_state(ptg_env* env, int field, const void* in_host);
  * device only if a launch that can finish episodes (a generic / terminating step) ran since the last call. */
 int ptg_finished_episodes(ptg_env* env, double* returns_host, int32_t* lengths_host, int32_t* env_ids_host,
                           int cap, int* count);
+/* When can the next episode end?  A batch whose envs share one step count (reset together, stepped together -- every batch until a
+ * partial reset or ptg_set_state de-synchronises it) ends its episodes on ONE known vector step (:508-511): *steps = the number of
+ * vector steps from now up to and including that one (>= 1).  *steps = 0: not known to the host (an episode may end on any step).
+ * A sharded job uses it to issue the episodic-return all-gather only in windows that contain an episode boundary. */
+int ptg_steps_to_episode_end(ptg_env* env, int* steps);
+/* Finished episodes that were never handed out since ptg_create: overwritten in the ring before a query came, or cut off by a
+ * query's `cap`.  0 for every caller that queries at least once per 2 * n_envs finished episodes with cap >= that. */
+int ptg_finished_dropped(ptg_env* env, uint64_t* dropped_total);
 
 /* ---- VecNormalize(env, norm_obs=False) reward normalisation on the device ------------------------------------------
  * Replaces: stable_baselines3.common.vec_env.VecNormalize.step_wait / _update_reward / normalize_reward and

@@ -59,7 +59,7 @@ STATE_FIELDS = {"meth_state": 0, "i": 1, "j": 2, "k": 3, "hot_cold": 4, "standby
 
 EXPORTS = ["ptg_abi_version", "ptg_create", "ptg_destroy", "ptg_num_envs", "ptg_obs_dim", "ptg_last_error",
            "ptg_set_market_assignment", "ptg_set_episode_plan", "ptg_set_noise_tape", "ptg_set_noise_rng", "ptg_set_global_env_offset", "ptg_fill_noise_tape",
-           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_profile", "ptg_profile_read", "ptg_sync", "ptg_get_state", "ptg_set_state",
+           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_host_buffers_changed", "ptg_profile", "ptg_profile_read", "ptg_profile_read_ex", "ptg_finished_dropped", "ptg_steps_to_episode_end", "ptg_sync", "ptg_get_state", "ptg_set_state",
            "ptg_finished_episodes", "ptg_vn_init", "ptg_vn_batch_moments", "ptg_vn_apply", "ptg_vn_get", "ptg_vn_set",
            "ptg_market_feature_series", "ptg_debug_get_index_lut", "ptg_debug_window_record"]
 
@@ -113,6 +113,12 @@ def lib():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(rl_ptg_amd has no CPU fallback)")
     L = C.CDLL(LIB_PATH)
+    L.ptg_abi_version.restype = C.c_int
+    import re
+    want = int(re.search(r"#define PTG_ABI_VERSION (\d+)", open(HDR).read()).group(1))
+    if L.ptg_abi_version() != want:      # e.g. a stale experiment build behind PTG_LIB_PATH
+        raise RuntimeError(f"{LIB_PATH} has ABI version {L.ptg_abi_version()}, include/ptg_env.h declares {want}: rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     vp, dp, u8p, i32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     L.ptg_abi_version.restype = C.c_int
     L.ptg_create.argtypes = [C.POINTER(PtgConfig), C.POINTER(PtgTables), C.POINTER(PtgMarket), C.c_int, C.c_int, C.c_int,
@@ -137,8 +143,12 @@ def lib():
     L.ptg_rollout_launches.argtypes = [vp, C.c_int]
     L.ptg_step_host.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_int), vp]
     L.ptg_host_layout.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ptg_host_buffers_changed.argtypes = [vp]
     L.ptg_profile.argtypes = [vp, C.c_int]
     L.ptg_profile_read.argtypes = [vp, dp, C.c_int, C.POINTER(C.c_int)]
+    L.ptg_profile_read_ex.argtypes = [vp, dp, dp, dp, C.c_int, C.POINTER(C.c_int)]
+    L.ptg_finished_dropped.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ptg_steps_to_episode_end.argtypes = [vp, C.POINTER(C.c_int)]
     L.ptg_sync.argtypes = [vp, vp]
     L.ptg_get_state.argtypes = [vp, C.c_int, vp]
     L.ptg_set_state.argtypes = [vp, C.c_int, vp]

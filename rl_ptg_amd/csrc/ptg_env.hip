@@ -1346,25 +1346,34 @@ __device__ __forceinline__ void pc_load_market(const HotParams& P, unsigned hb4,
 // inline asm into one never-read register quartet -- fire and forget.  It shares no vmcnt queue with the rollout's waves (an
 // in-order queue: a slow refresh load would hold back the gathers behind it; and a ninth wave inside the rollout's workgroup
 // caps the kernel at 168 registers, which spills), and it ends by itself after passes x period: no flag, no polling.
-__global__ void __launch_bounds__(64)
-k_refresh(const void* __restrict__ recf, const unsigned short* __restrict__ rkey, int n_rec, int passes, unsigned period)
+// this part's 1 / parts share of the [records | keys] image, as 1 KiB rows (64 lanes x 16 bytes), `waves` waves taking rows in turn
+__device__ __forceinline__ void refresh_rows(const void* __restrict__ recs, const unsigned short* __restrict__ rkey, unsigned n_rec, unsigned part,
+                                             unsigned parts, unsigned wave, unsigned waves, unsigned lane, uv4& sink)
 {
-    const unsigned lane = threadIdx.x;
-    const unsigned n16_rec = (unsigned)n_rec * 4u, n16 = n16_rec + ((unsigned)n_rec * 2u + 15u) / 16u;      // 16-byte pieces: records, then keys
-    const unsigned rows = (n16 + 63u) / 64u, per = (rows + gridDim.x - 1) / gridDim.x;                   // 1 KiB rows; this workgroup's share
-    const unsigned r_lo = min(rows, blockIdx.x * per), r_hi = min(rows, r_lo + per);
+    const unsigned n16_rec = n_rec * 4u, n16 = n16_rec + (n_rec * 2u + 15u) / 16u;                       // 16-byte pieces: records, then keys
+    const unsigned rows = (n16 + 63u) / 64u, per = (rows + parts - 1) / parts;
+    const unsigned r_lo = min(rows, part * per), r_hi = min(rows, r_lo + per);
+    for (unsigned row = r_lo + wave; row < r_hi; row += waves) {
+        const unsigned g = min(row * 64u + lane, n16 - 1u);
+        const char* src = g < n16_rec ? (const char*)recs + (size_t)g * 16u : (const char*)rkey + (size_t)(g - n16_rec) * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src) : "memory");
+    }
+}
+
+// Pass p (p = p0 .. passes - 1) starts p periods after the kernel did.  p0 = 1: the launch's head pass is done by the rollout kernel
+// itself, in its prologue (k_rollout_pc, `refresh_rec`), and this kernel -- forked from the rollout's stream right before it, so it
+// starts when the rollout does -- only adds the rolling passes of a long launch over a batch that is still a front.
+__global__ void __launch_bounds__(64)
+k_refresh(const void* __restrict__ recf, const unsigned short* __restrict__ rkey, int n_rec, int p0, int passes, unsigned period)
+{
     uv4 sink = {0u, 0u, 0u, 0u};
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (int p = 0; p < passes; p++) {
-        for (unsigned row = r_lo; row < r_hi; row++) {
-            const unsigned g = min(row * 64u + lane, n16 - 1u);
-            const char* src = g < n16_rec ? (const char*)recf + (size_t)g * 16u : (const char*)rkey + (size_t)(g - n16_rec) * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src) : "memory");
-        }
-        if (p + 1 < passes) {                               // pace: the next pass starts (p + 1) periods after the first (the clock only runs forward)
-            const unsigned long long target = t0 + (unsigned long long)(p + 1) * period;
+    for (int p = p0; p < passes; p++) {
+        if (p > 0) {                                        // pace (the clock only runs forward)
+            const unsigned long long target = t0 + (unsigned long long)p * period;
             while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(64);
         }
+        refresh_rows(recf, rkey, (unsigned)n_rec, blockIdx.x, gridDim.x, 0u, 1u, threadIdx.x, sink);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" :: "v"(sink));
@@ -1402,7 +1411,7 @@ template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT, bo
 __global__ void __launch_bounds__(512)
 k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows,
-             double* __restrict__ info)
+             double* __restrict__ info, int refresh_rec)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT, SPLIT = LAY == PTG_OBS_SPLIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -1413,6 +1422,14 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     PcSlot* slot = (PcSlot*)(s_dyn + 16 * ((sizeof(HotLds) + 15) / 16));
     typedef typename HotTypes<OUT>::rec_t rec_t;
     constexpr unsigned B = sizeof(OUT);
+    // The head pass of the table refresher (see k_refresh), inside this kernel's own duration: workgroup b re-reads its 1 / gridDim share
+    // of the records + keys (33 KiB at 256 workgroups) with fire-and-forget loads, the first thing it does -- they fly while the lookup
+    // table and the action rows are staged and have landed in the L2s / the Infinity Cache before the first gather (the prologue's
+    // barrier waits for them).  refresh_rec = 0: the host found nothing to refresh (little written since the last pass).
+    uv4 rsink = {0u, 0u, 0u, 0u};
+    if (refresh_rec)
+        refresh_rows(rec_table(P, (const rec_t*)nullptr), rkey, (unsigned)refresh_rec, blockIdx.x, gridDim.x, threadIdx.x >> 6, blockDim.x >> 6,
+                     threadIdx.x & 63u, rsink);
     OUT* s_tiles = (OUT*)((unsigned char*)slot + 2 * sizeof(PcSlot));                   // row-major: one [64][F] tile per consumer wave
     // float64 outputs: the 26 (17) per-env market features of the current hour live in LDS, [feature][env] -- as registers they
     // are 52 of the 256 a lane may have, and the kernel spilled.  The two 13-hour windows are rings: slot of element q = (q + head) mod 13
@@ -1531,6 +1548,10 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     PTG_STAMP(1);
     hot_stage_lds(P, L);
     PTG_STAMP(2);
+    if (refresh_rec) {                                      // (uniform) the refresh loads have landed: their target registers are free again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(rsink));
+    }
     __syncthreads();
     PTG_STAMP(3);
     const unsigned short* lut = LDSLUT ? s_lut : nullptr;
@@ -1911,22 +1932,32 @@ struct ptg_env {
     size_t vn_partials_cap = 0; int vn_T_cap = 0;
     double vn_gamma = 0.99, vn_eps = 1e-8, vn_clip = 10.0;
     bool fin_maybe = false;      // a generic step ran since the last ptg_finished_episodes: only those can finish episodes
+    unsigned long long fin_dropped = 0;      // finished episodes never handed out: ring overflow, or a query whose cap was too small
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
     int* d_eps_ind = nullptr;
     // experiment knobs, read from the environment ONCE in ptg_create (PTG_NO_HOT_KERNELS, PTG_NO_LDS_LUT, PTG_NO_REFRESH, PTG_REFRESH_ALWAYS, PTG_PC_CHUNK, PTG_BLOCK)
     bool knob_no_hot = false, knob_no_lds_lut = false, knob_no_refresh = false, knob_refresh_always = false;
+    int knob_refresh_mode = 0;   // PTG_REFRESH_MODE: 0 head pass in the rollout's prologue + forked rolling passes (default), 1 "legacy" (round 2:
+                                 // k_refresh enqueued ahead of the rollout, unordered), 2 "head" (no rolling passes)
     int front_horizon = 0;       // steps after a synchronised reset during which the table refresher keeps rolling (k_refresh)
     hipStream_t ref_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the refresher's stream is forked from / joined to the caller's (also under capture)
+    double unrefreshed_bytes = 1e18;      // written by this handle's kernels since the tables were last re-read (first launch: refresh)
+    int n_cu = 256;
+    std::vector<const void*> attr_done;   // kernels whose dynamic-LDS limit has been raised on this handle's device
     int* err_host = nullptr;     // DevParams::err as the host sees it
     // ptg_step_host: device staging for batches too large for zero-copy, and the classification of the caller's buffers
     void *hs_act = nullptr, *hs_out = nullptr, *hs_final = nullptr; double* hs_info = nullptr;
-    const void* hs_seen[4] = {nullptr, nullptr, nullptr, nullptr}; void* hs_dev[4] = {nullptr, nullptr, nullptr, nullptr}; bool hs_zero_copy = false;
+    struct HostPtr { const void* host = nullptr; void* dev = nullptr; };      // dev == nullptr: not device-mapped (pageable, or not host memory)
+    HostPtr hs_map[8]; int hs_next = 0;      // classification of the caller's buffers by address: a small round-robin cache (a VecEnv rotates 4 blocks)
     int knob_chunk = 65536, knob_block = 0;
     // per-launch timing (ptg_profile): kernel-attached start / stop events of the launches since profiling was switched on
     double* rollout_info = nullptr;   // set by ptg_rollout_info around its hot launches: the [T][N][24] info matrix (float64 kernels only)
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_used, prof_free;
+    struct ProfRec { hipEvent_t e0 = nullptr, e1 = nullptr, h0 = nullptr, h1 = nullptr; };      // the launch's events; its helper's (k_refresh), if any
+    std::vector<ProfRec> prof_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
     std::string err;
 };
 
@@ -1985,15 +2016,33 @@ int launch_check(ptg_env* h, const char* what)
 
 // ptg_profile: a (start, stop) event pair attached to the next kernel launch (hipExtLaunchKernelGGL stamps them at the kernel's
 // own begin / end, like the profiler's dispatch timestamps: no host launch latency inside the interval); nulls when off
+bool prof_events(ptg_env* h, hipEvent_t& e0, hipEvent_t& e1)
+{
+    std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
+    if (!h->prof_free.empty()) { p = h->prof_free.back(); h->prof_free.pop_back(); }
+    else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) { (void)hipGetLastError(); return false; }
+    e0 = p.first; e1 = p.second;
+    return true;
+}
+
 void prof_pair(ptg_env* h, hipEvent_t& e0, hipEvent_t& e1)
 {
     e0 = e1 = nullptr;
-    if (!h->profiling) return;
-    std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
-    if (!h->prof_free.empty()) { p = h->prof_free.back(); h->prof_free.pop_back(); }
-    else if (hipEventCreate(&p.first) != hipSuccess || hipEventCreate(&p.second) != hipSuccess) return;
-    h->prof_used.push_back(p);
-    e0 = p.first; e1 = p.second;
+    if (!h->profiling || !prof_events(h, e0, e1)) return;
+    ptg_env::ProfRec r;
+    r.e0 = e0; r.e1 = e1;
+    h->prof_used.push_back(r);
+}
+
+// the event pair of a helper kernel (k_refresh) that runs beside the NEXT profiled launch: remembered until that launch's record exists
+thread_local hipEvent_t g_helper0 = nullptr, g_helper1 = nullptr;
+
+// raise the dynamic-LDS limit of a kernel once per handle (= once per device the handle lives on)
+void lds_attr_once(ptg_env* h, const void* kfn, int bytes)
+{
+    for (const void* q : h->attr_done) if (q == kfn) return;
+    (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    h->attr_done.push_back(kfn);
 }
 
 int build_tables(ptg_env* h, const ptg_tables* tb)
@@ -2254,27 +2303,73 @@ PcPlan pc_plan(const ptg_env* h)
     return pl;
 }
 
-// k_refresh beside a hot rollout launch of m envs x tn steps that starts at step count k0 (see k_refresh).  One pass over the
-// tables per ~192 MB of output (the Infinity Cache holds 256 MB).  The rolling passes only while a synchronised batch is still
-// walking the tables as a front (the first front_horizon steps of an episode; PTG_REFRESH_ALWAYS: a policy that keeps the envs in
-// lock-step): afterwards the envs' own gathers keep every line warm, and one pass at the head of the launch covers whatever
-// other work evicted meanwhile.  Not while `st` is being captured into a graph (the refresher would run at capture time).
-void launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
+// The table refresher around a hot rollout launch of m envs x tn steps that starts at step count k0 (see k_refresh).  Returns the
+// `refresh_rec` argument of the rollout kernel: the record count when the launch is to re-read the tables in its prologue, else 0.
+//   head pass  -- whenever this handle's kernels have written more than ~64 MB since the tables were last re-read (every launch at
+//                 65 536 envs; every ~100 steps at 4 096): inside the rollout kernel, so inside its measured duration.
+//   rolling    -- one pass per ~192 MB of output (the Infinity Cache holds 256 MB), only while a synchronised batch is still walking
+//                 the tables as a front (the first front_horizon steps of an episode; PTG_REFRESH_ALWAYS: a policy that keeps the envs
+//                 in lock-step) and only in launches long enough to need one: k_refresh on a stream FORKED from `st` (event on `st`
+//                 before the rollout launch -> the refresher starts when the rollout does, whatever else `st` was busy with) and, while
+//                 `st` is being captured into a graph, JOINED again behind the rollout (join_refresher) -- a parallel branch of the graph.
+struct RefreshPlan { int head_rec = 0; bool forked = false; };
+
+RefreshPlan launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
 {
-    if (h->knob_no_refresh || !h->ref_stream) return;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    RefreshPlan rp;
     const int osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
-    const double step_bytes = (double)m * (h->F * osz + osz + 1);
+    const double step_bytes = (double)m * (h->F * osz + osz + 1), launch_bytes = step_bytes * tn;
+    if (h->knob_no_refresh) return rp;
+    const bool legacy = h->knob_refresh_mode == 1;
     const double pass_steps = std::max(8.0, 192e6 / step_bytes);
-    const bool roll = h->knob_refresh_always || k0 < h->front_horizon;
-    const int passes = roll ? std::max(1, (int)std::ceil(tn / pass_steps)) : 1;
+    const bool roll = (h->knob_refresh_always || k0 < h->front_horizon) && h->knob_refresh_mode != 2;
+    int passes;                                             // k_refresh's pass count (pass 0 = the head pass, only "legacy" runs it there)
+    if (legacy) passes = roll ? std::max(1, (int)std::ceil(tn / pass_steps)) : 1;
+    else {
+        const bool head = h->unrefreshed_bytes + launch_bytes >= 64e6;
+        if (head) { rp.head_rec = (int)h->rec_total; h->unrefreshed_bytes = 0.0; }
+        passes = (roll && tn > 4) ? 1 + (int)((tn - 4) / pass_steps) : 1;      // a pass with fewer than 4 steps left to serve is not issued
+        h->unrefreshed_bytes += launch_bytes - (passes - 1) * pass_steps * step_bytes;
+    }
+    if (!h->ref_stream || (!legacy && passes < 2)) return rp;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return rp; }
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    if (legacy && capturing) return rp;
+    if (!legacy) {                                          // fork
+        if (!h->ev_fork || hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->ref_stream, h->ev_fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return rp;
+        }
+        rp.forked = capturing;
+    }
     const double step_us = std::max(0.9, step_bytes / 6.2e6);                 // the rollout's pace: its output stream at ~6.2 TB/s, >= the producers' chain
     const unsigned period = (unsigned)std::min(4.0e6, pass_steps * step_us * 100.0);      // ticks of the 100 MHz clock; <= 40 ms
     const long long n16 = (long long)h->rec_total * 4 + ((long long)h->rec_total * 2 + 15) / 16;
-    const int grid = (int)std::min<long long>(256, (n16 + 63) / 64);
-    hipLaunchKernelGGL(k_refresh, dim3(grid), dim3(64), 0, h->ref_stream, osz == 8 ? (const void*)h->P.rec : (const void*)h->P.recf,
-                       (const unsigned short*)h->d_rkey, (int)h->rec_total, passes, period);
+    const int grid = (int)std::min<long long>(h->n_cu, (n16 + 63) / 64);
+    const void* recs = osz == 8 ? (const void*)h->P.rec : (const void*)h->P.recf;
+    hipEvent_t h0 = nullptr, h1 = nullptr;
+    if (h->profiling && !capturing && prof_events(h, h0, h1)) {
+        g_helper0 = h0; g_helper1 = h1;
+        hipExtLaunchKernelGGL(k_refresh, dim3(grid), dim3(64), 0, h->ref_stream, h0, h1, 0, recs, (const unsigned short*)h->d_rkey, (int)h->rec_total,
+                              legacy ? 0 : 1, passes, period);
+    } else
+        hipLaunchKernelGGL(k_refresh, dim3(grid), dim3(64), 0, h->ref_stream, recs, (const unsigned short*)h->d_rkey, (int)h->rec_total,
+                           legacy ? 0 : 1, passes, period);
+    return rp;
+}
+
+void join_refresher(ptg_env* h, hipStream_t st, const RefreshPlan& rp)
+{
+    if (!rp.forked) return;                                 // eager: k_refresh ends by itself, nothing waits for it
+    if (hipEventRecord(h->ev_join, h->ref_stream) != hipSuccess || hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) (void)hipGetLastError();
+}
+
+// attach the helper's events (if one was just launched) to the profile record of the launch it runs beside
+void prof_attach_helper(ptg_env* h)
+{
+    if (g_helper0 && !h->prof_used.empty()) { h->prof_used.back().h0 = g_helper0; h->prof_used.back().h1 = g_helper1; }
+    g_helper0 = g_helper1 = nullptr;
 }
 
 }  // namespace
@@ -2304,32 +2399,34 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
             const int m = std::min(chunk, h->n - e0);
             const dim3 grid(grid_for(m, np)), block(bs_all);
             const bool full = m % np == 0;
-            launch_refresher(h, st, m, tn, k0);
+            const RefreshPlan rp = launch_refresher(h, st, m, tn, k0);
+            const int rr = rp.head_rec;
 #define PTG_PC2(LL, FULL)                                                                                             \
     do {                                                                                                              \
         auto kfn = k_rollout_pc<LAY, MOD, NOISE, LL, FULL, OUT>;                                                      \
-        static int attr_dev = -1;      /* > 64 KiB of dynamic LDS needs the attribute: once per instantiation and device */ \
-        if (attr_dev != h->device) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_dev = h->device; } \
+        lds_attr_once(h, (const void*)kfn, (int)lds_max);      /* > 64 KiB of dynamic LDS needs the attribute */      \
         if (h->profiling) {                                                                                           \
             hipEvent_t pe0, pe1;                                                                                      \
             prof_pair(h, pe0, pe1);                                                                                   \
+            prof_attach_helper(h);                                                                                    \
             hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)sh, st, pe0, pe1, 0, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, \
-                                  (const unsigned short*)h->d_lut16, (const unsigned short*)h->d_rkey, e0, vec_rows, i_s); \
+                                  (const unsigned short*)h->d_lut16, (const unsigned short*)h->d_rkey, e0, vec_rows, i_s, rr); \
         } else                                                                                                        \
-            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s); \
+            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s, rr); \
     } while (0)
 #define PTG_PC(LL) do { if (full) PTG_PC2(LL, true); else PTG_PC2(LL, false); } while (0)
             bool launched = false;
             if constexpr (std::is_same<OUT, double>::value) {
                 if (i_s) {                                  // the eval info stream: one variant (lookup in global memory, any batch size)
                     auto kfn = k_rollout_pc<LAY, MOD, NOISE, false, false, double, true>;
-                    static int attr_dev_i = -1;
-                    if (attr_dev_i != h->device) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); attr_dev_i = h->device; }
-                    hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s);
+                    lds_attr_once(h, (const void*)kfn, (int)lds_max);
+                    hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s, rr);
                     launched = true;
                 }
             }
             if (!launched) { if (ll) PTG_PC(true); else PTG_PC(false); }
+            g_helper0 = g_helper1 = nullptr;
+            join_refresher(h, st, rp);
 #undef PTG_PC
 #undef PTG_PC2
         }
@@ -2401,11 +2498,17 @@ hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 int check_error_flags(ptg_env* h)          // after the stream has been synchronised
 {
-    volatile int* e = h->err_host;
-    const int bad_action = e[0], bad_range = e[1];
-    if (bad_action | bad_range) {
-        e[0] = 0; e[1] = 0;
-        if (bad_action) return set_err(h, PTG_E_ACTION, "a discrete action outside [-5, 4] was passed (the reference raises IndexError)");
+    // each word is exchanged with 0 on its own, and only the one being reported: a flag that another stream's kernel raises between
+    // the read and the clear of the OTHER word is not lost, and a pending RANGE error is reported by the next call
+    int* e = h->err_host;
+    if (__atomic_load_n(&e[0], __ATOMIC_RELAXED)) {
+        __atomic_exchange_n(&e[0], 0, __ATOMIC_RELAXED);
+        const bool also = __atomic_load_n(&e[1], __ATOMIC_RELAXED) != 0;
+        return set_err(h, PTG_E_ACTION, "a discrete action outside [-5, 4] was passed (the reference raises IndexError)%s", also ?
+                       "; a price-index error (PTG_E_RANGE) is pending as well and will be reported by the next call" : "");
+    }
+    if (__atomic_load_n(&e[1], __ATOMIC_RELAXED)) {
+        __atomic_exchange_n(&e[1], 0, __ATOMIC_RELAXED);
         return set_err(h, PTG_E_RANGE, "a price index left the market series (episode longer than the data)");
     }
     return 0;
@@ -2434,6 +2537,8 @@ void ptg_destroy(ptg_env* env)
     (void)hipSetDevice(env->device);
     (void)hipDeviceSynchronize();                           // nothing of this handle (incl. the refresher's stream) is in flight any more
     if (env->ref_stream) (void)hipStreamDestroy(env->ref_stream);
+    if (env->ev_fork) (void)hipEventDestroy(env->ev_fork);
+    if (env->ev_join) (void)hipEventDestroy(env->ev_join);
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->d_tape) (void)hipFree(env->d_tape);
     if (env->d_eps_ind) (void)hipFree(env->d_eps_ind);
@@ -2442,8 +2547,9 @@ void ptg_destroy(ptg_env* env)
     if (env->vn_moments) (void)hipFree(env->vn_moments);
     if (env->err_host) (void)hipHostFree(env->err_host);
     for (void* q : {env->hs_act, env->hs_out, env->hs_final, (void*)env->hs_info}) if (q) (void)hipFree(q);
-    for (auto* v : {&env->prof_used, &env->prof_free})
-        for (auto& p : *v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto& r : env->prof_used)
+        for (hipEvent_t e : {r.e0, r.e1, r.h0, r.h1}) if (e) (void)hipEventDestroy(e);
+    for (auto& p : env->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete env;
 }
 
@@ -2469,6 +2575,12 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     h->cfg = *cfg; h->n = n_envs; h->device = device_id; h->n_sets = n_sets;
     h->knob_no_hot = getenv("PTG_NO_HOT_KERNELS") != nullptr; h->knob_no_lds_lut = getenv("PTG_NO_LDS_LUT") != nullptr;
     h->knob_no_refresh = getenv("PTG_NO_REFRESH") != nullptr; h->knob_refresh_always = getenv("PTG_REFRESH_ALWAYS") != nullptr;
+    if (const char* v = getenv("PTG_REFRESH_MODE")) h->knob_refresh_mode = !strcmp(v, "legacy") ? 1 : !strcmp(v, "head") ? 2 : 0;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+        else (void)hipGetLastError();
+    }
     if (const char* v = getenv("PTG_PC_CHUNK")) h->knob_chunk = atoi(v);
     if (const char* v = getenv("PTG_BLOCK")) { const int b = atoi(v); if (b == 128 || b == 256 || b == 512) h->knob_block = b; }
     h->S = (int)((double)cfg->sim_step / (double)cfg->time_step_op);     // :66
@@ -2618,6 +2730,10 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&h->ref_stream, hipStreamNonBlocking, hi) != hipSuccess) { h->ref_stream = nullptr; (void)hipGetLastError(); }
+        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->ref_stream) { (void)hipStreamDestroy(h->ref_stream); h->ref_stream = nullptr; }     // no fork / join events: no rolling passes
+        }
     }
     if (hipDeviceSynchronize() != hipSuccess) { set_err(h, PTG_E_HIP, "device synchronize failed after init"); return fail(PTG_E_HIP); }
     *out = h;
@@ -2920,6 +3036,13 @@ int ptg_rollout_launches(ptg_env* h, int n_steps)
     return launches;
 }
 
+int ptg_steps_to_episode_end(ptg_env* h, int* steps)
+{
+    if (!h || !steps) return set_err(h, PTG_E_INVALID, "bad argument");
+    *steps = h->sync_k >= 0 ? (h->cfg.eps_sim_steps - 6) - h->sync_k + 1 : 0;
+    return 0;
+}
+
 // ---- the SB3-facing form of a step: host buffers in, host buffers out, one call ---------------------------------------
 int ptg_host_layout(const ptg_env* h, size_t* off_rew, size_t* off_done, size_t* total)
 {
@@ -2945,30 +3068,37 @@ int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* o
     const size_t final_bytes = (size_t)h->n * h->F * osz, info_bytes = (size_t)h->n * PTG_N_INFO * sizeof(double);
     // Small batches: the kernels read the actions from and write their outputs to the caller's pinned buffers directly (zero
     // copy: no DMA descriptors, one launch + one synchronise per step).  Large ones: device staging, one copy each way.
+    // A buffer's classification is cached by its address (8 entries): the caller keeps a buffer registered / allocated for as long as
+    // it passes it here, and calls ptg_host_buffers_changed() before re-using an ADDRESS for memory of another kind.
     const void* ptrs[4] = {actions_host, out_host, final_obs_host, info_host};
-    if (memcmp(ptrs, h->hs_seen, sizeof ptrs) != 0) {          // a new set of buffers: classify once
-        bool mapped = total + final_bytes <= (256u << 10);
-        for (int q = 0; q < 4 && mapped; q++) {
-            h->hs_dev[q] = nullptr;
-            if (!ptrs[q]) continue;
+    void* devp[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool zc = total + final_bytes + (info_host ? info_bytes : 0) + (size_t)h->n * asz <= (256u << 10);
+    for (int q = 0; q < 4 && zc; q++) {
+        if (!ptrs[q]) continue;
+        const ptg_env::HostPtr* hit = nullptr;
+        for (const auto& m : h->hs_map) if (m.host == ptrs[q]) { hit = &m; break; }
+        if (!hit) {
             hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, ptrs[q]) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer) { (void)hipGetLastError(); mapped = false; }
-            else h->hs_dev[q] = at.devicePointer;
+            ptg_env::HostPtr& m = h->hs_map[h->hs_next];
+            h->hs_next = (h->hs_next + 1) % 8;
+            m.host = ptrs[q]; m.dev = nullptr;
+            if (hipPointerGetAttributes(&at, ptrs[q]) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) m.dev = at.devicePointer;
+            else (void)hipGetLastError();
+            hit = &m;
         }
-        h->hs_zero_copy = mapped;
-        memcpy(h->hs_seen, ptrs, sizeof ptrs);
-        if (!mapped) {
-            if (!h->hs_act) HIP_TRY(h, hipMalloc(&h->hs_act, (size_t)h->n * 8));
-            if (!h->hs_out) HIP_TRY(h, hipMalloc(&h->hs_out, total));
-            if (!h->hs_final) HIP_TRY(h, hipMalloc(&h->hs_final, final_bytes));
-            if (info_host && !h->hs_info) HIP_TRY(h, hipMalloc((void**)&h->hs_info, info_bytes));
-        }
+        devp[q] = hit->dev;
+        zc = zc && hit->dev != nullptr;
     }
-    const bool zc = h->hs_zero_copy;
-    const void* d_act = zc ? h->hs_dev[0] : h->hs_act;
-    char* d_out = (char*)(zc ? h->hs_dev[1] : h->hs_out);
-    void* d_final = final_obs_host ? (zc ? h->hs_dev[2] : h->hs_final) : nullptr;
-    double* d_info = info_host ? (zc ? (double*)h->hs_dev[3] : h->hs_info) : nullptr;
+    if (!zc) {
+        if (!h->hs_act) HIP_TRY(h, hipMalloc(&h->hs_act, (size_t)h->n * 8));
+        if (!h->hs_out) HIP_TRY(h, hipMalloc(&h->hs_out, total));
+        if (!h->hs_final) HIP_TRY(h, hipMalloc(&h->hs_final, final_bytes));
+        if (info_host && !h->hs_info) HIP_TRY(h, hipMalloc((void**)&h->hs_info, info_bytes));
+    }
+    const void* d_act = zc ? devp[0] : h->hs_act;
+    char* d_out = (char*)(zc ? devp[1] : h->hs_out);
+    void* d_final = final_obs_host ? (zc ? devp[2] : h->hs_final) : nullptr;
+    double* d_info = info_host ? (zc ? (double*)devp[3] : h->hs_info) : nullptr;
     if (!zc) HIP_TRY(h, hipMemcpyAsync(h->hs_act, actions_host, (size_t)h->n * asz, hipMemcpyHostToDevice, st));
     int rc = ptg_step(h, d_act, action_kind, d_out, d_out + o_rew, (uint8_t*)(d_out + o_done), d_final, d_info, stream);
     if (rc) return rc;
@@ -2991,6 +3121,14 @@ int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* o
         HIP_TRY(h, hipStreamSynchronize(st));
     }
     *n_done = cnt;
+    return 0;
+}
+
+int ptg_host_buffers_changed(ptg_env* h)
+{
+    if (!h) return PTG_E_INVALID;
+    for (auto& m : h->hs_map) m = ptg_env::HostPtr();
+    h->hs_next = 0;
     return 0;
 }
 
@@ -3092,7 +3230,10 @@ int ptg_profile(ptg_env* h, int enable)
 {
     if (!h) return PTG_E_INVALID;
     if (enable && !h->profiling) {                          // a fresh collection
-        for (auto& p : h->prof_used) h->prof_free.push_back(p);
+        for (auto& r : h->prof_used) {
+            h->prof_free.push_back({r.e0, r.e1});
+            if (r.h0) h->prof_free.push_back({r.h0, r.h1});
+        }
         h->prof_used.clear();
         while (h->prof_free.size() < 16) {                  // event pairs created here, not inside the first timed launch
             std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
@@ -3104,23 +3245,40 @@ int ptg_profile(ptg_env* h, int enable)
     return 0;
 }
 
-int ptg_profile_read(ptg_env* h, double* us_host, int cap, int* count)
+int ptg_profile_read_ex(ptg_env* h, double* us_host, double* helper_us_host, double* span_us_host, int cap, int* count)
 {
     if (!h || !count || cap < 0 || (cap > 0 && !us_host)) return set_err(h, PTG_E_INVALID, "ptg_profile_read: bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     int n = 0;
-    for (auto& p : h->prof_used) {
-        HIP_TRY(h, hipEventSynchronize(p.second));
+    for (auto& r : h->prof_used) {
+        HIP_TRY(h, hipEventSynchronize(r.e1));
         float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, p.first, p.second));
-        if (n < cap) us_host[n] = (double)ms * 1e3;
+        HIP_TRY(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+        double us = (double)ms * 1e3, helper = 0.0, span = us;
+        if (r.h0) {                                         // the union of [launch] and [its helper]: from the earlier start to the later end
+            HIP_TRY(h, hipEventSynchronize(r.h1));
+            float hm = 0.f, d0 = 0.f, d1 = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&hm, r.h0, r.h1));
+            HIP_TRY(h, hipEventElapsedTime(&d0, r.e0, r.h0));      // helper start - launch start (negative: the helper started first)
+            HIP_TRY(h, hipEventElapsedTime(&d1, r.e1, r.h1));      // helper end - launch end
+            helper = (double)hm * 1e3;
+            span = us + std::max(0.0, (double)d1 * 1e3) - std::min(0.0, (double)d0 * 1e3);
+            h->prof_free.push_back({r.h0, r.h1});
+        }
+        if (n < cap) {
+            us_host[n] = us;
+            if (helper_us_host) helper_us_host[n] = helper;
+            if (span_us_host) span_us_host[n] = span;
+        }
         n++;
-        h->prof_free.push_back(p);
+        h->prof_free.push_back({r.e0, r.e1});
     }
     h->prof_used.clear();
     *count = std::min(n, cap);
     return 0;
 }
+
+int ptg_profile_read(ptg_env* h, double* us_host, int cap, int* count) { return ptg_profile_read_ex(h, us_host, nullptr, nullptr, cap, count); }
 
 int ptg_sync(ptg_env* h, void* stream)
 {
@@ -3243,6 +3401,7 @@ int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_hos
     HIP_TRY(h, hipMemcpy(&total, h->P.fin_count, sizeof(unsigned), hipMemcpyDeviceToHost));
     const int have = (int)std::min<unsigned>(total, (unsigned)h->P.fin_cap);
     const int n = std::min(have, cap);
+    h->fin_dropped += (unsigned long long)(total - (unsigned)have) + (unsigned long long)(have - n);      // the list is cleared below either way
     // entries [total - have, total) are live (ring); hand out the oldest n of them: at most two contiguous pieces
     if (n > 0) {
         const int cap_r = h->P.fin_cap, s0 = (int)((total - (unsigned)have) % (unsigned)cap_r);
@@ -3262,6 +3421,13 @@ int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_hos
     }
     HIP_TRY(h, hipMemset(h->P.fin_count, 0, sizeof(int)));
     *count = n;
+    return 0;
+}
+
+int ptg_finished_dropped(ptg_env* h, uint64_t* dropped_total)
+{
+    if (!h || !dropped_total) return set_err(h, PTG_E_INVALID, "bad argument");
+    *dropped_total = h->fin_dropped;
     return 0;
 }
 

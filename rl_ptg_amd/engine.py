@@ -261,6 +261,28 @@ class HipEngine:
         self._chk(self._L.ptg_profile_read(self._h, _dp(out), cap, C.byref(cnt)))
         return out[:cnt.value].copy()
 
+    def profile_read_ex(self, cap=65536):
+        """profile_read with each launch's helper kernel (the table refresher beside it) accounted for: (us, helper_us, span_us),
+        span = first start to last end of the launch and its helper (include/ptg_env.h, ptg_profile_read_ex)."""
+        us, hp, sp = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        cnt = C.c_int(0)
+        self._chk(self._L.ptg_profile_read_ex(self._h, _dp(us), _dp(hp), _dp(sp), cap, C.byref(cnt)))
+        n = cnt.value
+        return us[:n].copy(), hp[:n].copy(), sp[:n].copy()
+
+    def finished_dropped(self):
+        """Finished episodes that were never handed out (ring overflow / a query's cap) since the engine was created."""
+        d = C.c_uint64(0)
+        self._chk(self._L.ptg_finished_dropped(self._h, C.byref(d)))
+        return int(d.value)
+
+    def steps_to_episode_end(self):
+        """Vector steps from now up to and including the one on which a synchronised batch's episodes end; 0 = unknown to the
+        host (de-synchronised batch).  Pure host bookkeeping: no device call."""
+        s = C.c_int(0)
+        self._chk(self._L.ptg_steps_to_episode_end(self._h, C.byref(s)))
+        return int(s.value)
+
     def sync(self):
         self._chk(self._L.ptg_sync(self._h, self._stream()))
 

@@ -57,8 +57,8 @@ lines = [f"# rocprofv3 summary, {tag}", "",
          "(K launches replayed as one hipGraph), `ptg_rollout` with feature-major observations and with float64 row-major observations (`<row,f64>`).",
          "Dispatches of `k_rollout_pc<row>` in trace order:",
          f"the W-step warm-up launch from reset, THE TIMED {K}-step LAUNCH (bench.py's `roofline.avg_launch_us`), then the two 400-step",
-         "steady-state launches (`steady_state`); `k_rollout_pc<feature>`: warm-up, timed.  `k_refresh` is the table refresher that runs beside",
-         "every rollout launch on its own stream (DESIGN.md section 5).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the",
+         "steady-state rollouts (`steady_state`; 250 + 150 steps each); `k_rollout_pc<feature>`: warm-up, timed.  `k_refresh` is the table refresher's",
+         "rolling-pass kernel (forked from the rollout's stream; only for launches long enough to need one, DESIGN.md section 5).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the",
          "same command with `--launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads); counter unit KiB.", "",
          "| kernel | dispatches | avg us | min us | max us | VGPR | SGPR | LDS B | scratch | block | grid |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 for k in sorted(trace, key=lambda x: -sum(v[1] for v in trace[x])):
@@ -73,6 +73,26 @@ for k in sorted(trace):
         lines.append(f"`{k}` dispatches in order [us]: " + ", ".join(f"{x / 1e3:.1f}" for x in d) +
                      (f"  -> timed {K}-step launch: **{d[1] / 1e3:.1f} us** = {d[1] / 1e3 / K:.3f} us per step" if len(d) > 1 else "") +
                      (f"; second 400-step steady rollout: {sum(d[2 + (len(d) - 2) // 2:]) / 1e3:.1f} us = {sum(d[2 + (len(d) - 2) // 2:]) / 1e3 / 400:.3f} us per step" if len(d) > 3 else ""))
+# start / end stamps of the headline launch and of every table-refresher dispatch near it (the interval bench.py reports
+# is the union of the two; since round 3 the pass at the head of a launch runs INSIDE the rollout kernel and no k_refresh precedes it)
+hk = "k_rollout_pc<row>"
+if hk in trace and len(trace[hk]) > 1:
+    disp = sorted(trace[hk])
+    refs = sorted(trace.get("k_refresh", []))
+    lines += ["", f"Dispatch stamps around `{hk}` (ns, relative to the start of the timed {K}-step launch; from the kernel trace):", "",
+              "| dispatch | start | end | duration us |", "|---|---|---|---|"]
+    t0 = disp[1][0]
+    for name, lst in (("k_rollout_pc<row> warm-up launch", disp[0:1]), (f"k_rollout_pc<row> TIMED {K}-step launch", disp[1:2]),
+                      ("k_rollout_pc<row> next launch (steady_state leg)", disp[2:3])):
+        for st, du in lst:
+            lines.append(f"| {name} | {st - t0} | {st + du - t0} | {du / 1e3:.2f} |")
+    near = [(st, du) for st, du in refs if disp[0][0] - 50000 <= st <= (disp[2][0] + disp[2][1] if len(disp) > 2 else disp[1][0] + disp[1][1] + 50000)]
+    for st, du in near:
+        lines.append(f"| k_refresh | {st - t0} | {st + du - t0} | {du / 1e3:.2f} |")
+    inside = [1 for st, du in refs if st + du > disp[1][0] - 20000 and st < disp[1][0] + disp[1][1]]
+    lines.append("")
+    lines.append(f"k_refresh dispatches that end within 20 us before the timed launch or overlap it: **{len(inside)}**" +
+                 (" (the head pass is inside the rollout kernel; rolling passes only in launches long enough to need one)" if not inside else ""))
 # the bench line of the PROFILED run: its own event-based figures for the same launches
 try:
     line = [l for l in open(f"gpurun_out/prof_{tag}_trace.log") if l.startswith("{")][-1]
@@ -84,7 +104,8 @@ try:
               "profiled process runs 8-10 % slower than an un-profiled one (steady state 1.60-1.65 vs 1.47-1.53 us per step; MI355X_MICROARCH.md, DVFS",
               "give-back item 2: never compare a profiled arm with an un-profiled one).  The un-profiled driver-argument run is profiles/r02_bench_driver_args.json."]
     for nme, r in legs:
-        lines.append(f"* {nme}: avg_launch_us = {r['avg_launch_us']:.2f} over {r['launches_timed']} launch(es), frac = {r['frac']:.3f}")
+        lines.append(f"* {nme}: avg_launch_us = {r['avg_launch_us']:.2f} over {r['launches_timed']} launch(es), frac = {r['frac']:.3f}" +
+                     (f" (kernel only {r['kernel_only_us']:.2f} us, refresher beside it {r['refresh_us']:.2f} us)" if "kernel_only_us" in r else ""))
     if "steady_state" in bj:
         lines.append(f"* steady_state: {bj['steady_state']['us_per_step']:.3f} us per step, frac = {bj['steady_state']['frac']:.3f}")
 except Exception as e:
