@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--p-switch", type=float, default=1.0 / 12.0, help="per-step probability of drawing a new action")
     ap.add_argument("--noise", choices=["rng", "tape"], default="rng", help="in-kernel counter RNG or a device-filled tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mixed-scenarios", action="store_true",
+                    help="BASELINE.json configs[4]'s per-rank leg: business scenarios 1, 2, 3 mixed inside the batch (global env e -> scenario e %% 3), one operation level")
     ap.add_argument("--no-boundary-leg", dest="boundary_leg", action="store_false",
                     help="skip the episode_boundary leg (a window that contains the episode end + the finished-episode all-gather)")
     args = ap.parse_args()
@@ -200,7 +202,18 @@ def main():
     coll_stream = torch.cuda.Stream(device=device)
     K, W, n = args.steps, args.warmup, args.envs
     n_total = n * world
-    spec, _ = synthetic_spec(scenario=args.scenario, operation=args.operation, eps_len_d=32)
+    if args.mixed_scenarios:
+        from rl_ptg_amd.prep import EnvSpec
+        spec = EnvSpec.merge_scenarios([synthetic_spec(scenario=sc, operation=args.operation, eps_len_d=32)[0] for sc in (1, 2, 3)])
+    else:
+        spec, _ = synthetic_spec(scenario=args.scenario, operation=args.operation, eps_len_d=32)
+
+    def configure(eng):
+        """what every leg's fresh handle gets: this rank's place in the job (episode plan, RNG streams, scenario mix)"""
+        eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
+        eng.set_global_env_offset(first_ptr - n_total)
+        if args.mixed_scenarios:
+            eng.set_market_assignment(ptg_dist.mixed_scenario_assignment(n_total, world, rank, len(spec.markets)))
     first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
     STEADY_T = 400
 
@@ -209,8 +222,7 @@ def main():
         torch.cuda.empty_cache()                              # each leg starts from a fresh allocator state (no recycled multi-GB blocks)
         eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=out_dtype, obs_layout=layout)
         F = eng.obs_dim
-        eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
-        eng.set_global_env_offset(first_ptr - n_total)
+        configure(eng)
         if args.noise == "rng":
             eng.set_noise_rng(seed=20250614)                  # counter-based draws inside the kernels
         else:
@@ -300,7 +312,8 @@ def main():
             else:
                 r_all, l_all = r, l
         tD = time.perf_counter()
-        torch.cuda.synchronize()
+        eng.sync()                                 # ptg_sync: polls the stream (no interrupt wake-up latency), then reports kernel-flagged errors
+        torch.cuda.synchronize()                   # (the contract's synchronise: nothing is left to wait for)
         elapsed = time.perf_counter() - t_start    # this rank's time since the common start (barrier + synchronize); MAX over ranks below
         if os.environ.get("PTG_BENCH_DEBUG"):
             print("timed region pieces us: ev0 %.0f run %.0f fin+gather %.0f sync %.0f total %.0f" % ((tA - t_start) * 1e6, (tB - tA) * 1e6, (tD - tB) * 1e6, (time.perf_counter() - tD) * 1e6, elapsed * 1e6), file=sys.stderr)
@@ -420,8 +433,7 @@ def main():
         all-gather of the episodic returns over the ranks -- the one collective of the path, at the one place it belongs."""
         torch.cuda.empty_cache()
         eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
-        eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
-        eng.set_global_env_offset(first_ptr - n_total)
+        configure(eng)
         eng.set_noise_rng(seed=20250614)
         F = eng.obs_dim
         acts = sticky_actions_device(chunk + B, n, seed=4321 + rank, device=device, p_switch=args.p_switch)
@@ -490,7 +502,7 @@ def main():
             "dtype": ("f32 observations / rewards" if args.out_dtype == "float32" else "f64 observations / rewards") +
                      "; env state, reward coefficients and cum_rew in f64",
             "data": "synthetic",
-            "config": {"workload": f"N={n} envs/GPU, BS{args.scenario}/{args.operation}, synthetic 38-day trace (32-day episodes), "
+            "config": {"workload": f"N={n} envs/GPU, {'BS1+BS2+BS3 mixed (env e -> scenario e % 3)' if args.mixed_scenarios else 'BS' + str(args.scenario)}/{args.operation}, synthetic 38-day trace (32-day episodes), "
                                    f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), noise: {args.noise}",
                        "path": head["path"], "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype,
                        "obs_dim": res["F"], "obs_layout": args.obs_layout, "parallelism": f"env-sharded x{world}, no per-step collective"},

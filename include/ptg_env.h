@@ -28,7 +28,8 @@ extern "C" {
 #endif
 
 #define PTG_ABI_VERSION 4   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series;
-                             * 4: + ptg_profile_read_ex, ptg_finished_dropped, ptg_host_buffers_changed, ptg_steps_to_episode_end */
+                             * 4: + ptg_profile_read_ex, ptg_finished_dropped, ptg_host_buffers_changed, ptg_steps_to_episode_end,
+                             *    ptg_host_layout_ex (status section), ptg_step_host_begin / _tail / _end / _finish */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -198,6 +199,22 @@ int ptg_rollout_info(ptg_env* env, const void* actions_dev, int action_kind, int
 int ptg_host_layout(const ptg_env* env, size_t* off_rew, size_t* off_done, size_t* total);
 int ptg_step_host(ptg_env* env, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
                   int* n_done, void* stream);
+/* The out_host block has a fourth section since ABI 4 (ptg_host_layout's `total` includes it): "status" [N] uint8 at off_status = the
+ * METH_STATUS of every env's returned observation row, contiguous -- what a NumPy caller turns into the int64 METH_STATUS vector of
+ * the Dict observation (:219-249) without gathering one column out of N rows. */
+int ptg_host_layout_ex(const ptg_env* env, size_t* off_rew, size_t* off_done, size_t* off_status, size_t* total);
+/* ptg_step_host in three phases, for a caller with work of its own to overlap (VecEnv.step_async / step_wait):
+ *   ptg_step_host_begin  enqueues everything on `stream` and returns: actions in, the step kernel(s), the outputs back -- as two copies
+ *                        for staged batches, [rewards | done flags | status] (+ info rows) first, the observations behind them;
+ *   ptg_step_host_tail   waits until rewards, done flags, status (and info rows) are in out_host and counts the finished envs -- the
+ *                        observations of a large batch are still crossing PCIe while the caller works on the small part;
+ *   ptg_step_host_end    waits for the observations, reports kernel-flagged errors (PTG_E_ACTION / PTG_E_RANGE), and fetches the terminal
+ *                        observations when episodes ended.  One host step at a time per handle; ptg_step_host == begin + tail + end. */
+int ptg_step_host_begin(ptg_env* env, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
+                        void* stream);
+int ptg_step_host_tail(ptg_env* env, int* n_done);
+int ptg_step_host_end(ptg_env* env);
+int ptg_step_host_finish(ptg_env* env, int* n_done);      /* tail + end in one call */
 /* ptg_step_host remembers, per buffer ADDRESS (the last 8), whether the buffer is device-mapped pinned memory.  A buffer must stay
  * allocated / registered for as long as it is passed to ptg_step_host; a caller that frees one and later passes memory of another
  * kind at the same address calls this first (forgets the classifications). */

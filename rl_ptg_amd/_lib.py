@@ -10,7 +10,7 @@ SRC = os.path.join(PKG, "csrc", "ptg_env.hip")
 HDR = os.path.join(ROOT, "include", "ptg_env.h")
 LIB_PATH = os.environ.get("PTG_LIB_PATH") or os.path.join(PKG, "lib", "libptg_env.so")      # PTG_LIB_PATH: an experiment build of the same source
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall"]
-N_PARTS = 7          # translation units of the parallel build: -DPTG_PART=0..6 (ptg_env.hip, "PTG_PART")
+N_PARTS = 9          # translation units of the parallel build: -DPTG_PART=0..8 (ptg_env.hip, "PTG_PART")
 
 N_TABLES, N_INFO = 17, 24
 ACT_I32, ACT_F32, ACT_I64 = 0, 1, 2
@@ -59,7 +59,7 @@ STATE_FIELDS = {"meth_state": 0, "i": 1, "j": 2, "k": 3, "hot_cold": 4, "standby
 
 EXPORTS = ["ptg_abi_version", "ptg_create", "ptg_destroy", "ptg_num_envs", "ptg_obs_dim", "ptg_last_error",
            "ptg_set_market_assignment", "ptg_set_episode_plan", "ptg_set_noise_tape", "ptg_set_noise_rng", "ptg_set_global_env_offset", "ptg_fill_noise_tape",
-           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_host_buffers_changed", "ptg_profile", "ptg_profile_read", "ptg_profile_read_ex", "ptg_finished_dropped", "ptg_steps_to_episode_end", "ptg_sync", "ptg_get_state", "ptg_set_state",
+           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_host_layout_ex", "ptg_step_host_begin", "ptg_step_host_tail", "ptg_step_host_end", "ptg_step_host_finish", "ptg_host_buffers_changed", "ptg_profile", "ptg_profile_read", "ptg_profile_read_ex", "ptg_finished_dropped", "ptg_steps_to_episode_end", "ptg_sync", "ptg_get_state", "ptg_set_state",
            "ptg_finished_episodes", "ptg_vn_init", "ptg_vn_batch_moments", "ptg_vn_apply", "ptg_vn_get", "ptg_vn_set",
            "ptg_market_feature_series", "ptg_debug_get_index_lut", "ptg_debug_window_record"]
 
@@ -143,6 +143,11 @@ def lib():
     L.ptg_rollout_launches.argtypes = [vp, C.c_int]
     L.ptg_step_host.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.POINTER(C.c_int), vp]
     L.ptg_host_layout.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ptg_host_layout_ex.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 4
+    L.ptg_step_host_begin.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+    L.ptg_step_host_tail.argtypes = [vp, C.POINTER(C.c_int)]
+    L.ptg_step_host_end.argtypes = [vp]
+    L.ptg_step_host_finish.argtypes = [vp, C.POINTER(C.c_int)]
     L.ptg_host_buffers_changed.argtypes = [vp]
     L.ptg_profile.argtypes = [vp, C.c_int]
     L.ptg_profile_read.argtypes = [vp, dp, C.c_int, C.POINTER(C.c_int)]

@@ -16,6 +16,7 @@
 #include "../../include/ptg_env.h"
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -798,6 +799,7 @@ __global__ void k_build_fast(const DevParams P, const Rec* __restrict__ in, RecF
 template <typename T>
 __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) { return *(const T*)((const char*)base + byte_off); }
 typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+typedef double vd2 __attribute__((ext_vector_type(2)));
 // Output rows (observations, rewards, done flags) are written once and never read back by these kernels: non-temporal
 // stores keep the write stream from allocating in L2, where it evicts the window records and market series every step
 // re-reads (measured at N = 65 536: 2.86 -> 1.90 us per fused step, and the producer / consumer form 2.96 -> 1.51).
@@ -1175,13 +1177,14 @@ struct RowTile {
                 const int g = lane + 64 * j;
                 if (g < N4 && (!PARTIAL || g < n16)) __builtin_nontemporal_store(((const vf4*)t)[g], (vf4*)rows + g);
             }
-        } else {                                            // padded pitch (float32 SB3_FLAT rows): four 4-byte LDS reads per piece; two pieces
+        } else {                                            // padded pitch (SB3_FLAT / SPLIT rows): EPP element-sized LDS reads per piece; two pieces
 #pragma unroll 2                                            // in flight keep the kernel inside its register budget
             for (int j = 0; j < (N4 + 63) / 64; j++) {
                 const int g = lane + 64 * j;
                 if (g < N4 && (!PARTIAL || g < n16)) {
-                    const float* src = (const float*)t + (g / (F / 4)) * PITCH + (g % (F / 4)) * 4;
-                    __builtin_nontemporal_store(vf4{src[0], src[1], src[2], src[3]}, (vf4*)rows + g);
+                    const OUT* src = t + (g / (F / EPP)) * PITCH + (g % (F / EPP)) * EPP;      // F is a multiple of EPP: a piece never straddles two rows
+                    if constexpr (EPP == 4) __builtin_nontemporal_store(vf4{(float)src[0], (float)src[1], (float)src[2], (float)src[3]}, (vf4*)rows + g);
+                    else __builtin_nontemporal_store(vd2{(double)src[0], (double)src[1]}, (vd2*)rows + g);
                 }
             }
         }
@@ -1765,6 +1768,23 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     }
 }
 
+// METH_STATUS of every env's observation row as one contiguous byte array (ptg_step_host's "status" section): the NumPy side of a
+// VecEnv needs it as an int64 vector, and gathering column 26 of 65 536 rows of 140 bytes on the host costs more than the step.
+// c0 = the column that holds it (row / feature-major), or the first of its six one-hot columns (SB3_FLAT / SPLIT rows).
+template <typename OUT>
+__global__ void __launch_bounds__(256) k_pack_status(const OUT* __restrict__ obs, int N, int F, int c0, int fm, int onehot, uint8_t* __restrict__ status)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    int v;
+    if (onehot) {
+        v = 0;
+#pragma unroll
+        for (int j = 1; j < 6; j++) v += obs[(size_t)e * F + c0 + j] != (OUT)0 ? j : 0;
+    } else v = (int)(fm ? obs[(size_t)c0 * N + e] : obs[(size_t)e * F + c0]);
+    status[e] = (uint8_t)v;
+}
+
 __global__ void k_extract_keys(const RecFast* __restrict__ recf, unsigned short* __restrict__ rkey, int n)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1938,6 +1958,7 @@ struct ptg_env {
     int* d_eps_ind = nullptr;
     // experiment knobs, read from the environment ONCE in ptg_create (PTG_NO_HOT_KERNELS, PTG_NO_LDS_LUT, PTG_NO_REFRESH, PTG_REFRESH_ALWAYS, PTG_PC_CHUNK, PTG_BLOCK)
     bool knob_no_hot = false, knob_no_lds_lut = false, knob_no_refresh = false, knob_refresh_always = false;
+    bool knob_capture_fork = false;      // PTG_REFRESH_CAPTURE_FORK: capture k_refresh as a forked branch of the graph (measured slower: the branches replay serially)
     int knob_refresh_mode = 0;   // PTG_REFRESH_MODE: 0 head pass in the rollout's prologue + forked rolling passes (default), 1 "legacy" (round 2:
                                  // k_refresh enqueued ahead of the rollout, unordered), 2 "head" (no rolling passes)
     int front_horizon = 0;       // steps after a synchronised reset during which the table refresher keeps rolling (k_refresh)
@@ -1949,6 +1970,14 @@ struct ptg_env {
     int* err_host = nullptr;     // DevParams::err as the host sees it
     // ptg_step_host: device staging for batches too large for zero-copy, and the classification of the caller's buffers
     void *hs_act = nullptr, *hs_out = nullptr, *hs_final = nullptr; double* hs_info = nullptr;
+    struct HostStep {            // a ptg_step_host call between its phases (begin .. tail .. end)
+        bool active = false, zc = false, tail_done = false;
+        void* out_host = nullptr; void* final_host = nullptr; double* info_host = nullptr;
+        hipStream_t st = nullptr;
+        int n_done = 0;
+    } hs;
+    int status_col_flat = 5;           // SB3_FLAT rows: first of the six one-hot METH_STATUS columns (ptg_create, from the column map)
+    hipEvent_t ev_tail = nullptr;      // recorded behind the copy of [rewards | done flags | status] (+ info rows): the part the caller needs first
     struct HostPtr { const void* host = nullptr; void* dev = nullptr; };      // dev == nullptr: not device-mapped (pageable, or not host memory)
     HostPtr hs_map[8]; int hs_next = 0;      // classification of the caller's buffers by address: a small round-robin cache (a VecEnv rotates 4 blocks)
     int knob_chunk = 65536, knob_block = 0;
@@ -2240,10 +2269,8 @@ HotParams make_hot_params(const ptg_env* h)
 // the hot kernels apply to a 13-hour look-ahead, a synchronised batch, and steps on which no env terminates
 bool hot_eligible(const ptg_env* h)
 {
-    // (SB3's flattened rows are float32 by construction: float64 SB3_FLAT rows stay with the generic kernels)
     const unsigned long long osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
-    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && !((h->flat || h->split) && osz == 8) &&
-           (unsigned long long)h->n * h->F * osz < 0xFFFFFFFFull;
+    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && (unsigned long long)h->n * h->F * osz < 0xFFFFFFFFull;
 }
 
 int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
@@ -2306,12 +2333,16 @@ PcPlan pc_plan(const ptg_env* h)
 // The table refresher around a hot rollout launch of m envs x tn steps that starts at step count k0 (see k_refresh).  Returns the
 // `refresh_rec` argument of the rollout kernel: the record count when the launch is to re-read the tables in its prologue, else 0.
 //   head pass  -- whenever this handle's kernels have written more than ~64 MB since the tables were last re-read (every launch at
-//                 65 536 envs; every ~100 steps at 4 096): inside the rollout kernel, so inside its measured duration.
+//                 65 536 envs; every ~100 steps at 4 096): inside the rollout kernel, so inside its measured duration -- and inside a
+//                 captured graph.
 //   rolling    -- one pass per ~192 MB of output (the Infinity Cache holds 256 MB), only while a synchronised batch is still walking
 //                 the tables as a front (the first front_horizon steps of an episode; PTG_REFRESH_ALWAYS: a policy that keeps the envs
 //                 in lock-step) and only in launches long enough to need one: k_refresh on a stream FORKED from `st` (event on `st`
-//                 before the rollout launch -> the refresher starts when the rollout does, whatever else `st` was busy with) and, while
-//                 `st` is being captured into a graph, JOINED again behind the rollout (join_refresher) -- a parallel branch of the graph.
+//                 before the rollout launch -> the refresher starts when the rollout does, whatever else `st` was busy with).
+//                 NOT while `st` is being captured: the fork / join captures fine (a parallel branch of the graph), but the runtime
+//                 replays the two branches one after the other -- 150 steps from reset took 420 us as a graph against 253 us eager
+//                 (tests/test_batch_edges.py, round 3) -- so a captured launch keeps the head pass only (+ 8 % on the first ~250 steps
+//                 after a reset, profiles/r03_refresh_ab.txt).  PTG_REFRESH_CAPTURE_FORK=1 brings the captured branch back.
 struct RefreshPlan { int head_rec = 0; bool forked = false; };
 
 RefreshPlan launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
@@ -2324,18 +2355,19 @@ RefreshPlan launch_refresher(ptg_env* h, hipStream_t st, int m, int tn, int k0)
     const double pass_steps = std::max(8.0, 192e6 / step_bytes);
     const bool roll = (h->knob_refresh_always || k0 < h->front_horizon) && h->knob_refresh_mode != 2;
     int passes;                                             // k_refresh's pass count (pass 0 = the head pass, only "legacy" runs it there)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    const bool capturing = cs != hipStreamCaptureStatusNone;
+    const bool may_roll = roll && !(capturing && !h->knob_capture_fork);
     if (legacy) passes = roll ? std::max(1, (int)std::ceil(tn / pass_steps)) : 1;
     else {
         const bool head = h->unrefreshed_bytes + launch_bytes >= 64e6;
         if (head) { rp.head_rec = (int)h->rec_total; h->unrefreshed_bytes = 0.0; }
-        passes = (roll && tn > 4) ? 1 + (int)((tn - 4) / pass_steps) : 1;      // a pass with fewer than 4 steps left to serve is not issued
+        passes = (may_roll && tn > 4) ? 1 + (int)((tn - 4) / pass_steps) : 1;      // a pass with fewer than 4 steps left to serve is not issued
         h->unrefreshed_bytes += launch_bytes - (passes - 1) * pass_steps * step_bytes;
     }
     if (!h->ref_stream || (!legacy && passes < 2)) return rp;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return rp; }
-    const bool capturing = cs != hipStreamCaptureStatusNone;
-    if (legacy && capturing) return rp;
+    if (capturing && (legacy || !h->knob_capture_fork)) return rp;
     if (!legacy) {                                          // fork
         if (!h->ev_fork || hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->ref_stream, h->ev_fork, 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -2436,7 +2468,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
 }  // namespace ptg_hot
 
 // PTG_PART (the parallel build, rl_ptg_amd/_lib.py): part 0 holds the C ABI, the generic kernels and everything else, and only
-// DECLARES the hot launchers' instantiations; parts 1..6 each define those of one (layout, dtype).  Without PTG_PART this file is one
+// DECLARES the hot launchers' instantiations; parts 1..8 each define those of one (layout, dtype).  Without PTG_PART this file is one
 // self-contained translation unit (hipcc -shared ptg_env.hip: the diagnostic builds, anybody's quick build).
 #define PTG_HOT_INST1(X, LAY, OUT, MOD, NZ)                                                                                              \
     X template void ptg_hot::launch_step_hot<LAY, MOD, NZ, OUT>(ptg_env*, hipStream_t, const void*, int, OUT*, OUT*, uint8_t*);         \
@@ -2449,6 +2481,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
 #if PTG_PART == 0
 PTG_HOT_INST(extern, PTG_OBS_ROW_MAJOR, float) PTG_HOT_INST(extern, PTG_OBS_FEATURE_MAJOR, float) PTG_HOT_INST(extern, PTG_OBS_SB3_FLAT, float)
 PTG_HOT_INST(extern, PTG_OBS_SPLIT, float) PTG_HOT_INST(extern, PTG_OBS_ROW_MAJOR, double) PTG_HOT_INST(extern, PTG_OBS_FEATURE_MAJOR, double)
+PTG_HOT_INST(extern, PTG_OBS_SB3_FLAT, double) PTG_HOT_INST(extern, PTG_OBS_SPLIT, double)
 #elif PTG_PART == 1
 PTG_HOT_INST(PTG_NOTHING, PTG_OBS_ROW_MAJOR, float)
 #elif PTG_PART == 2
@@ -2461,8 +2494,12 @@ PTG_HOT_INST(PTG_NOTHING, PTG_OBS_SPLIT, float)
 PTG_HOT_INST(PTG_NOTHING, PTG_OBS_ROW_MAJOR, double)
 #elif PTG_PART == 6
 PTG_HOT_INST(PTG_NOTHING, PTG_OBS_FEATURE_MAJOR, double)
+#elif PTG_PART == 7
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_SB3_FLAT, double)
+#elif PTG_PART == 8
+PTG_HOT_INST(PTG_NOTHING, PTG_OBS_SPLIT, double)
 #else
-#error "PTG_PART must be 0..6"
+#error "PTG_PART must be 0..8"
 #endif
 #endif
 
@@ -2478,13 +2515,15 @@ using ptg_hot::launch_rollout_hot;
         if (nm_ == NOISE_TAPE) { if (mod_) FN<LAY_, true, NOISE_TAPE, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_TAPE, OUT_>(__VA_ARGS__); }      \
         else { if (mod_) FN<LAY_, true, NOISE_RNG, OUT_>(__VA_ARGS__); else FN<LAY_, false, NOISE_RNG, OUT_>(__VA_ARGS__); }   /* no noise source = the RNG kernels with sigma 0 (make_hot_params) */ \
     } while (0)
-// obs / rew arrive as void*: the element type is the handle's out_dtype (SB3_FLAT rows are float32 only, see hot_eligible)
+// obs / rew arrive as void*: the element type is the handle's out_dtype
 #define PTG_HOT_DISPATCH(FN, H_, ST_, A_, KIND_, CNT_ARGS_, OBS_, REW_, DONE_)                           \
     do {                                                                                                \
         const int nm_ = noise_mode(H_);                                                                 \
         const bool mod_ = (H_)->P.mod != 0;                                                             \
         if ((H_)->cfg.out_dtype == PTG_OUT_F64) {                                                       \
             if ((H_)->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_); \
+            else if ((H_)->flat) PTG_HOT_DISPATCH3(FN, PTG_OBS_SB3_FLAT, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_); \
+            else if ((H_)->split) PTG_HOT_DISPATCH3(FN, PTG_OBS_SPLIT, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_);   \
             else PTG_HOT_DISPATCH3(FN, PTG_OBS_ROW_MAJOR, double, H_, ST_, A_, KIND_ CNT_ARGS_, (double*)(OBS_), (double*)(REW_), DONE_);               \
         } else if ((H_)->fm) PTG_HOT_DISPATCH3(FN, PTG_OBS_FEATURE_MAJOR, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);  \
         else if ((H_)->flat) PTG_HOT_DISPATCH3(FN, PTG_OBS_SB3_FLAT, float, H_, ST_, A_, KIND_ CNT_ARGS_, (float*)(OBS_), (float*)(REW_), DONE_);       \
@@ -2514,9 +2553,26 @@ int check_error_flags(ptg_env* h)          // after the stream has been synchron
     return 0;
 }
 
+// Wait for `st`: poll for up to ~200 us (hipStreamQuery: no interrupt, no wake-up latency -- a blocking synchronise returns 20-30 us
+// after a short kernel has ended), then block.  A step or a short rollout is over long before the polling budget runs out.
+int wait_stream(ptg_env* h, hipStream_t st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return set_err(h, PTG_E_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        (void)hipGetLastError();                            // hipErrorNotReady is sticky in hipGetLastError()
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return 0;
+}
+
 int collect_error(ptg_env* h, hipStream_t st)
 {
-    HIP_TRY(h, hipStreamSynchronize(st));
+    const int rc = wait_stream(h, st);
+    if (rc) return rc;
     return check_error_flags(h);
 }
 
@@ -2539,6 +2595,7 @@ void ptg_destroy(ptg_env* env)
     if (env->ref_stream) (void)hipStreamDestroy(env->ref_stream);
     if (env->ev_fork) (void)hipEventDestroy(env->ev_fork);
     if (env->ev_join) (void)hipEventDestroy(env->ev_join);
+    if (env->ev_tail) (void)hipEventDestroy(env->ev_tail);
     for (void* p : env->allocs) (void)hipFree(p);
     if (env->d_tape) (void)hipFree(env->d_tape);
     if (env->d_eps_ind) (void)hipFree(env->d_eps_ind);
@@ -2575,6 +2632,7 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
     h->cfg = *cfg; h->n = n_envs; h->device = device_id; h->n_sets = n_sets;
     h->knob_no_hot = getenv("PTG_NO_HOT_KERNELS") != nullptr; h->knob_no_lds_lut = getenv("PTG_NO_LDS_LUT") != nullptr;
     h->knob_no_refresh = getenv("PTG_NO_REFRESH") != nullptr; h->knob_refresh_always = getenv("PTG_REFRESH_ALWAYS") != nullptr;
+    h->knob_capture_fork = getenv("PTG_REFRESH_CAPTURE_FORK") != nullptr;
     if (const char* v = getenv("PTG_REFRESH_MODE")) h->knob_refresh_mode = !strcmp(v, "legacy") ? 1 : !strcmp(v, "head") ? 2 : 0;
     {
         hipDeviceProp_t prop;
@@ -2624,6 +2682,7 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         int* d_cmap;
         if ((rc = dev_upload(h, &d_cmap, cmap.data(), cmap.size()))) return fail(rc);
         P.cmap = d_cmap; P.q_stat = o;
+        h->status_col_flat = cmap[o];
         h->F += 5; h->flat = true;
     }
     if (cfg->obs_layout == PTG_OBS_SPLIT) {               // env part of the flat row + series indices (include/ptg_env.h)
@@ -3044,30 +3103,63 @@ int ptg_steps_to_episode_end(ptg_env* h, int* steps)
 }
 
 // ---- the SB3-facing form of a step: host buffers in, host buffers out, one call ---------------------------------------
-int ptg_host_layout(const ptg_env* h, size_t* off_rew, size_t* off_done, size_t* total)
+int ptg_host_layout_ex(const ptg_env* h, size_t* off_rew, size_t* off_done, size_t* off_status, size_t* total)
 {
     if (!h) return PTG_E_INVALID;
     const size_t osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
     const size_t o_rew = ((size_t)h->n * h->F * osz + 15) / 16 * 16, o_done = (o_rew + (size_t)h->n * osz + 15) / 16 * 16;
+    const size_t o_status = (o_done + (size_t)h->n + 15) / 16 * 16;
     if (off_rew) *off_rew = o_rew;
     if (off_done) *off_done = o_done;
-    if (total) *total = (o_done + (size_t)h->n + 15) / 16 * 16;
+    if (off_status) *off_status = o_status;
+    if (total) *total = (o_status + (size_t)h->n + 15) / 16 * 16;
     return 0;
 }
 
-int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
-                  int* n_done, void* stream)
+int ptg_host_layout(const ptg_env* h, size_t* off_rew, size_t* off_done, size_t* total) { return ptg_host_layout_ex(h, off_rew, off_done, nullptr, total); }
+
+namespace {
+
+// where METH_STATUS sits in an observation row of this handle's layout (k_pack_status)
+void status_column(const ptg_env* h, int& c0, int& onehot)
+{
+    const int q_stat = h->cfg.raw_modified ? 2 * h->cfg.price_ahead : h->cfg.price_ahead + 4;      // canonical column (:219-249)
+    onehot = (h->flat || h->split) ? 1 : 0;
+    c0 = h->split ? 0 : q_stat;
+    if (h->flat) c0 = h->status_col_flat;                     // sorted-key order ('mod': CH4, Elec_Heating, H2O, H2_in, H2_res come first: column 5)
+}
+
+int wait_event(ptg_env* h, hipEvent_t ev)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return set_err(h, PTG_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+    }
+    HIP_TRY(h, hipEventSynchronize(ev));
+    return 0;
+}
+
+}  // namespace
+
+int ptg_step_host_begin(ptg_env* h, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host, void* stream)
 {
     if (!h) return PTG_E_INVALID;
-    if (!actions_host || !out_host || !n_done) return set_err(h, PTG_E_INVALID, "ptg_step_host: null buffer");
+    if (!actions_host || !out_host) return set_err(h, PTG_E_INVALID, "ptg_step_host: null buffer");
+    if (h->hs.active) return set_err(h, PTG_E_INVALID, "ptg_step_host_begin: the previous host step has not been ended (ptg_step_host_end)");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = as_stream(stream);
     const size_t osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4, asz = action_kind == PTG_ACT_I64 ? 8 : 4;
-    size_t o_rew, o_done, total;
-    ptg_host_layout(h, &o_rew, &o_done, &total);
+    size_t o_rew, o_done, o_status, total;
+    ptg_host_layout_ex(h, &o_rew, &o_done, &o_status, &total);
     const size_t final_bytes = (size_t)h->n * h->F * osz, info_bytes = (size_t)h->n * PTG_N_INFO * sizeof(double);
     // Small batches: the kernels read the actions from and write their outputs to the caller's pinned buffers directly (zero
-    // copy: no DMA descriptors, one launch + one synchronise per step).  Large ones: device staging, one copy each way.
+    // copy: no DMA descriptors, one launch + one synchronise per step).  Large ones: device staging; the outputs come back as TWO
+    // copies -- [rewards | done flags | status] (+ info rows) first, with an event behind them, then the observations -- so that the
+    // caller's work on the small part (ptg_step_host_tail) overlaps the 9-18 MB of observations still crossing PCIe.
     // A buffer's classification is cached by its address (8 entries): the caller keeps a buffer registered / allocated for as long as
     // it passes it here, and calls ptg_host_buffers_changed() before re-using an ADDRESS for memory of another kind.
     const void* ptrs[4] = {actions_host, out_host, final_obs_host, info_host};
@@ -3094,6 +3186,7 @@ int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* o
         if (!h->hs_out) HIP_TRY(h, hipMalloc(&h->hs_out, total));
         if (!h->hs_final) HIP_TRY(h, hipMalloc(&h->hs_final, final_bytes));
         if (info_host && !h->hs_info) HIP_TRY(h, hipMalloc((void**)&h->hs_info, info_bytes));
+        if (!h->ev_tail) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
     }
     const void* d_act = zc ? devp[0] : h->hs_act;
     char* d_out = (char*)(zc ? devp[1] : h->hs_out);
@@ -3103,25 +3196,97 @@ int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* o
     int rc = ptg_step(h, d_act, action_kind, d_out, d_out + o_rew, (uint8_t*)(d_out + o_done), d_final, d_info, stream);
     if (rc) return rc;
     if (!zc) {
-        HIP_TRY(h, hipMemcpyAsync(out_host, h->hs_out, total, hipMemcpyDeviceToHost, st));
+        int c0, onehot;
+        status_column(h, c0, onehot);
+        const dim3 grid(grid_for(h->n, 256)), block(256);
+        if (osz == 8) hipLaunchKernelGGL(k_pack_status<double>, grid, block, 0, st, (const double*)d_out, h->n, h->F, c0, h->fm ? 1 : 0, onehot, (uint8_t*)(d_out + o_status));
+        else hipLaunchKernelGGL(k_pack_status<float>, grid, block, 0, st, (const float*)d_out, h->n, h->F, c0, h->fm ? 1 : 0, onehot, (uint8_t*)(d_out + o_status));
+        if ((rc = launch_check(h, "k_pack_status"))) return rc;
+        HIP_TRY(h, hipMemcpyAsync((char*)out_host + o_rew, h->hs_out ? (char*)h->hs_out + o_rew : nullptr, total - o_rew, hipMemcpyDeviceToHost, st));
         if (info_host) HIP_TRY(h, hipMemcpyAsync(info_host, h->hs_info, info_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipEventRecord(h->ev_tail, st));
+        HIP_TRY(h, hipMemcpyAsync(out_host, h->hs_out, o_rew, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(h, hipStreamSynchronize(st));
-    if ((rc = check_error_flags(h))) return rc;
-    const uint8_t* dn = (const uint8_t*)out_host + o_done;
-    int cnt = 0;
-    size_t e = 0;
-    for (; e + 8 <= (size_t)h->n; e += 8) {                     // done flags are 0 / 1 bytes: sum eight at a time
-        uint64_t w; memcpy(&w, dn + e, 8);
-        if (w) cnt += __builtin_popcountll(w);
-    }
-    for (; e < (size_t)h->n; e++) cnt += dn[e] != 0;
-    if (cnt && !zc && final_obs_host) {                         // rare: the terminal observations of the episodes that just ended
-        HIP_TRY(h, hipMemcpyAsync(final_obs_host, h->hs_final, final_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
-    }
-    *n_done = cnt;
+    ptg_env::HostStep& hs = h->hs;
+    hs.active = true; hs.zc = zc; hs.tail_done = false; hs.out_host = out_host; hs.final_host = final_obs_host; hs.info_host = info_host;
+    hs.st = st; hs.n_done = 0;
     return 0;
+}
+
+int ptg_step_host_tail(ptg_env* h, int* n_done)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!h->hs.active) return set_err(h, PTG_E_INVALID, "ptg_step_host_tail: no host step in flight (ptg_step_host_begin)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ptg_env::HostStep& hs = h->hs;
+    int rc;
+    if (!hs.tail_done) {
+        if ((rc = hs.zc ? wait_stream(h, hs.st) : wait_event(h, h->ev_tail))) { hs.active = false; return rc; }
+        size_t o_rew, o_done, o_status, total;
+        ptg_host_layout_ex(h, &o_rew, &o_done, &o_status, &total);
+        const uint8_t* dn = (const uint8_t*)hs.out_host + o_done;
+        int cnt = 0;
+        size_t e = 0;
+        for (; e + 8 <= (size_t)h->n; e += 8) {                     // done flags are 0 / 1 bytes: sum eight at a time
+            uint64_t w; memcpy(&w, dn + e, 8);
+            if (w) cnt += __builtin_popcountll(w);
+        }
+        for (; e < (size_t)h->n; e++) cnt += dn[e] != 0;
+        hs.n_done = cnt;
+        if (hs.zc) {                                                // tiny batch, written in place: the status bytes from the rows themselves
+            int c0, onehot;
+            status_column(h, c0, onehot);
+            uint8_t* stt = (uint8_t*)hs.out_host + o_status;
+            const bool f64 = h->cfg.out_dtype == PTG_OUT_F64;
+            auto at = [&](size_t idx) -> double { return f64 ? ((const double*)hs.out_host)[idx] : (double)((const float*)hs.out_host)[idx]; };
+            for (int q = 0; q < h->n; q++) {
+                int v = 0;
+                if (onehot) { for (int j = 1; j < 6; j++) v += at((size_t)q * h->F + c0 + j) != 0.0 ? j : 0; }
+                else v = (int)(h->fm ? at((size_t)c0 * h->n + q) : at((size_t)q * h->F + c0));
+                stt[q] = (uint8_t)v;
+            }
+        }
+        hs.tail_done = true;
+    }
+    if (n_done) *n_done = hs.n_done;
+    return 0;
+}
+
+int ptg_step_host_end(ptg_env* h)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!h->hs.active) return set_err(h, PTG_E_INVALID, "ptg_step_host_end: no host step in flight (ptg_step_host_begin)");
+    ptg_env::HostStep& hs = h->hs;
+    int rc = hs.tail_done ? 0 : ptg_step_host_tail(h, nullptr);
+    hs.active = false;                                          // whatever happens below, the step is over
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((rc = wait_stream(h, hs.st))) return rc;
+    if ((rc = check_error_flags(h))) return rc;
+    if (hs.n_done && !hs.zc && hs.final_host) {                 // rare: the terminal observations of the episodes that just ended
+        const size_t final_bytes = (size_t)h->n * h->F * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);
+        HIP_TRY(h, hipMemcpyAsync(hs.final_host, h->hs_final, final_bytes, hipMemcpyDeviceToHost, hs.st));
+        HIP_TRY(h, hipStreamSynchronize(hs.st));
+    }
+    return 0;
+}
+
+int ptg_step_host_finish(ptg_env* h, int* n_done)      // tail + end in one call (small batches: nothing to overlap)
+{
+    const int rc = ptg_step_host_tail(h, n_done);
+    if (rc) return rc;
+    return ptg_step_host_end(h);
+}
+
+int ptg_step_host(ptg_env* h, const void* actions_host, int action_kind, void* out_host, void* final_obs_host, double* info_host,
+                  int* n_done, void* stream)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!n_done) return set_err(h, PTG_E_INVALID, "ptg_step_host: null buffer");
+    int rc = ptg_step_host_begin(h, actions_host, action_kind, out_host, final_obs_host, info_host, stream);
+    if (rc) return rc;
+    if ((rc = ptg_step_host_tail(h, n_done))) return rc;
+    return ptg_step_host_end(h);
 }
 
 int ptg_host_buffers_changed(ptg_env* h)

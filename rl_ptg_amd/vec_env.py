@@ -91,7 +91,11 @@ class PtGVecEnv(_VecEnvBase):
 
     def __init__(self, dict_input, n_envs, train_or_eval="train", seed=None, device=0, out_dtype="float64", obs_layout="row",
                  noise="numpy", noise_tape_len=256, world_size=1, rank=0, render_mode="None", engine_cls=HipEngine,
-                 norm_reward=False, gamma=0.99, epsilon=1e-8, clip_reward=10.0):
+                 norm_reward=False, gamma=0.99, epsilon=1e-8, clip_reward=10.0, copy_obs=None):
+        if obs_layout not in ("row", "feature"):
+            # the Dict observation is carved out of the canonical [N, F] matrix; SB3's flattened rows ("sb3_flat") and the split rows
+            # ("split") have other columns -- they belong to the tensor API (HipEngine.step / rollout, step_tensors)
+            raise ValueError(f"PtGVecEnv: obs_layout must be 'row' or 'feature', got {obs_layout!r} (use HipEngine for 'sb3_flat' / 'split' rows)")
         spec = dict_input if isinstance(dict_input, EnvSpec) else EnvSpec.from_dict_input(dict_input, train_or_eval)
         want = {"train": 0, "eval": 1}[train_or_eval]
         if int(spec.consts.get("train_or_eval", want)) != want:      # a prepared EnvSpec used for the other mode: the argument wins
@@ -134,6 +138,11 @@ class PtGVecEnv(_VecEnvBase):
         self.norm_reward = bool(norm_reward)
         self.training = True
         self._old_reward = None
+        # copy_obs: True = step() returns fresh arrays and a new infos list every step, like DummyVecEnv (_save_obs copies);
+        # False = views of a ring of OBS_RING pinned blocks (valid until step() has been called OBS_RING - 1 more times) and ONE
+        # persistent infos list whose entries are replaced in place; None = copies up to 64 KiB per step, views above (copying
+        # 9-18 MB and building a 65 536-entry list per step costs more than the step).  INTEGRATION.md, "Lifetime of what step() returns".
+        self._copy_obs_arg = copy_obs
         if self.norm_reward:
             self.engine.vn_init(gamma=gamma, epsilon=epsilon, clip_reward=clip_reward)
         self._setup_host()
@@ -188,12 +197,12 @@ class PtGVecEnv(_VecEnvBase):
         import ctypes as C
         import torch
         eng = self.engine
-        o_rew, o_done, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
-        eng._chk(eng._L.ptg_host_layout(eng._h, C.byref(o_rew), C.byref(o_done), C.byref(total)))
-        self._off_rew, self._off_done, self._blk_bytes = o_rew.value, o_done.value, total.value
+        o_rew, o_done, o_stat, total = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        eng._chk(eng._L.ptg_host_layout_ex(eng._h, C.byref(o_rew), C.byref(o_done), C.byref(o_stat), C.byref(total)))
+        self._off_rew, self._off_done, self._off_status, self._blk_bytes = o_rew.value, o_done.value, o_stat.value, total.value
         n, F = self.num_envs, eng.obs_dim
         self._odt = np.float64 if eng.out_dtype == torch.float64 else np.float32
-        self._copy_out = total.value <= (64 << 10)
+        self._copy_out = total.value <= (64 << 10) if self._copy_obs_arg is None else bool(self._copy_obs_arg)
         k = 1 if self._copy_out else self.OBS_RING
 
         def pinned(nbytes):
@@ -216,16 +225,20 @@ class PtGVecEnv(_VecEnvBase):
         self._final_ptr = C.c_void_p(self._final.ctypes.data)
         self._final_mat = self._final.reshape(F, n).T if eng.feature_major else self._final.reshape(n, F)
         self._info_host, self._info_ptr = None, None
+        self._lazy_info = eng.eval_mode and n > self.EAGER_INFO_MAX
         if eng.eval_mode:
-            self._info_host = pinned(n * 24 * 8).view(np.float64)[:n * 24].reshape(n, 24)
-            self._info_ptr = C.c_void_p(self._info_host.ctypes.data)
+            # large eval batches: TWO info blocks used in turn -- the rows of the latest step are read in place through _InfoRow (no
+            # 12.6 MB copy per step at 65 536 envs) while the next step's rows land in the other block
+            self._info_blocks = [pinned(n * 24 * 8).view(np.float64)[:n * 24].reshape(n, 24) for _ in range(2 if self._lazy_info else 1)]
+            self._info_ptrs = [C.c_void_p(b.ctypes.data) for b in self._info_blocks]
+            self._info_slot = 0
+            self._info_host, self._info_ptr = self._info_blocks[0], self._info_ptrs[0]
         self._n_done = C.c_int(0)
         self._n_done_ref = C.byref(self._n_done)
-        self._stream_ptr = eng._stream()
+        self._in_flight = None                                  # slot of the host step begun by step_async
         # infos: N persistent dicts, replaced only for envs whose episode ended (and put back empty on the next step)
         self._infos = [{} for _ in range(n)]
         self._dirty = []
-        self._lazy_info = eng.eval_mode and n > self.EAGER_INFO_MAX
         if self._lazy_info:
             self._infos = [_InfoRow(self, e) for e in range(n)]
         self._info_cur = None
@@ -238,16 +251,18 @@ class PtGVecEnv(_VecEnvBase):
         mat = flat.reshape(F, n).T if self.engine.feature_major else flat.reshape(n, F)
         rew = blk[self._off_rew:self._off_rew + n * np.dtype(self._odt).itemsize].view(self._odt)
         done = blk[self._off_done:self._off_done + n]
-        return mat, rew, done
+        status = blk[self._off_status:self._off_status + n]    # METH_STATUS of every row, contiguous bytes (ptg_host_layout_ex)
+        return mat, rew, done, status
 
     # ------------------------------------------------------------------ observations
-    def _obs_dict(self, mat, copy=True):
+    def _obs_dict(self, mat, copy=True, status=None):
         """[N, F] matrix (reference dict order) -> dict keyed like observation_space.  copy=False: column views of `mat`
-        (METH_STATUS is always a new int64 array).  Element type = the engine's out_dtype (float64 by default, as declared)."""
+        (METH_STATUS is always a new int64 array; `status` = that array, if the caller has already made it from the library's
+        contiguous status bytes).  Element type = the engine's out_dtype (float64 by default, as declared)."""
         out = {}
         for k, sl in self._key_slices:
             if k == "METH_STATUS":
-                out[k] = np.rint(mat[:, sl.start]).astype(np.int64)
+                out[k] = status if status is not None else np.rint(mat[:, sl.start]).astype(np.int64)
             else:
                 out[k] = np.array(mat[:, sl], copy=True) if copy else mat[:, sl]
         return out
@@ -302,6 +317,22 @@ class PtGVecEnv(_VecEnvBase):
             a = a.reshape(self.num_envs)
         np.copyto(self._act_buf, a, casting="unsafe")         # into the pinned block the kernel (or the H2D copy) reads
         self._actions = self._act_buf
+        if self.norm_reward:
+            return                                             # the device path enqueues in step_wait (_step_wait_device)
+        if self._needs_reset:
+            raise RuntimeError("PtGVecEnv: call reset() before step()")
+        # enqueue the whole step now (ptg_step_host_begin): actions in, kernel(s), outputs back; step_wait collects it.  The stream is
+        # torch's current stream at THIS call (a caller inside `with torch.cuda.stream(s)` gets its step on s)
+        eng = self.engine
+        slot = self._slot
+        self._slot = (slot + 1) % len(self._blk)
+        if self._lazy_info:
+            self._info_slot ^= 1
+            self._info_host, self._info_ptr = self._info_blocks[self._info_slot], self._info_ptrs[self._info_slot]
+        rc = eng._L.ptg_step_host_begin(eng._h, self._act_ptr, self._act_kind, self._blk_ptr[slot], self._final_ptr, self._info_ptr, eng._stream())
+        if rc:
+            eng._chk(rc)
+        self._in_flight = slot
 
     def _finish_infos(self, dones, n_done, final_mat):
         """Monitor / DummyVecEnv conventions for the envs whose episode ended; everything else keeps its persistent entry."""
@@ -312,7 +343,7 @@ class PtGVecEnv(_VecEnvBase):
             self._dirty = []
         if self.engine.eval_mode:
             if self._lazy_info:
-                self._info_cur = self._info_host.copy()       # rows are read through _InfoRow on demand
+                self._info_cur = self._info_host              # rows are read through _InfoRow on demand, in place (the next step fills the other block)
             else:
                 info = self._info_host
                 for e in range(self.num_envs):
@@ -338,19 +369,35 @@ class PtGVecEnv(_VecEnvBase):
         if self.norm_reward:
             return self._step_wait_device()
         eng = self.engine
-        slot = self._slot
-        self._slot = (slot + 1) % len(self._blk)
-        # ONE library call: actions in, kernel(s), outputs back, one synchronisation; raises on an invalid action (reference: IndexError)
-        rc = eng._L.ptg_step_host(eng._h, self._act_ptr, self._act_kind, self._blk_ptr[slot], self._final_ptr, self._info_ptr,
-                                  self._n_done_ref, self._stream_ptr)
-        if rc:
-            eng._chk(rc)
-        mat, rew, done = self._views[slot]
-        obs = self._obs_dict(mat, copy=self._copy_out)
-        rews = rew.astype(np.float32)                         # always a new array
-        dones = done.astype(bool)
+        slot = self._in_flight
+        if slot is None:
+            raise RuntimeError("PtGVecEnv: step_wait() without step_async()")
+        self._in_flight = None
+        mat, rew, done, status = self._views[slot]
+        if self._copy_out:                                    # small batch: nothing to overlap, one call (raises on an invalid action: reference IndexError)
+            rc = eng._L.ptg_step_host_finish(eng._h, self._n_done_ref)
+            if rc:
+                eng._chk(rc)
+            rews, dones, stat64 = rew.astype(np.float32), done.astype(bool), status.astype(np.int64)
+        else:
+            # phase 2 (ptg_step_host_tail): rewards, done flags and the METH_STATUS bytes are on the host; the observations of a large
+            # batch are still crossing PCIe while the arrays below are made
+            rc = eng._L.ptg_step_host_tail(eng._h, self._n_done_ref)
+            if rc:
+                eng._L.ptg_step_host_end(eng._h)
+                eng._chk(rc)
+            rews = rew.astype(np.float32)                     # always a new array
+            dones = done.astype(bool)
+            stat64 = status.astype(np.int64)
+            # phase 3 (ptg_step_host_end): observations in; raises on an invalid action (reference: IndexError)
+            rc = eng._L.ptg_step_host_end(eng._h)
+            if rc:
+                eng._chk(rc)
         self._old_reward = rews
+        obs = self._obs_dict(mat, copy=self._copy_out, status=stat64)
         infos = self._finish_infos(dones, self._n_done.value, self._final_mat)
+        if self._copy_out:
+            infos = list(infos)                               # a new list object every step (entries shared), like DummyVecEnv's deepcopy'd buf_infos
         if self.noise_mode == "numpy":
             self._steps_since_refill += 1
             if self._steps_since_refill >= self._tape_len:

@@ -58,7 +58,7 @@ def _run(spec, n, layout, out_dtype, acts, route):
 
 
 @pytest.mark.parametrize("layout,out_dtype", [("row", "float32"), ("feature", "float32"), ("sb3_flat", "float32"), ("split", "float32"),
-                                              ("row", "float64"), ("feature", "float64")])
+                                              ("row", "float64"), ("feature", "float64"), ("sb3_flat", "float64"), ("split", "float64")])
 def test_batch_sizes_at_wave_and_workgroup_boundaries(layout, out_dtype):
     from rl_ptg_amd.prep import synthetic_spec
     spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=8)
@@ -136,11 +136,18 @@ def test_rollout_captured_into_a_graph_and_replayed_once():
 
 @pytest.mark.parametrize("warm,Tg", [(5, 20), (0, 150)])
 def test_captured_rollout_keeps_the_table_refresher(warm, Tg):
-    """A rollout replayed as a hipGraph right after a synchronised reset is as fast as the eager call: the pass at the
-    head of a launch is part of the rollout kernel, and the rolling passes of a long launch (Tg = 150: k_refresh on its own stream) are
-    captured as a forked branch of the graph, joined behind the rollout.  65 536 envs, the bench's workload; (5, 20) is the driver's
-    window.  Both forms are timed the same way -- stream events recorded while a filler kernel keeps the stream busy, so no host launch
-    latency sits inside either interval -- and must agree within 10 % (+ 2 us); results bit-equal."""
+    """A rollout replayed as a hipGraph right after a synchronised reset keeps the table refresher: the pass at the head
+    of a launch is part of the rollout kernel, so a captured launch has it.  65 536 envs, the bench's workload; (5, 20) is the driver's
+    window, (0, 150) a long launch from reset.  Results: ONE replay == the eager call, bit for bit.  Time: the SECOND replay of the
+    graph (the first also pays the runtime's one-off graph set-up) against the eager call at the same place -- the second rollout after
+    the reset --, both timed by stream events recorded while a filler keeps the stream busy (no host launch latency inside either
+    interval).  Allowed: 10 % + 8 us for the 20-step window -- hipGraphLaunch itself puts 5-8 us between the event and the kernel
+    (tools/graph_probe.py: 48.8 vs 41.9 us for the same 20 steps, 246 vs 250 us for 150; without the refresher the 20 steps take 54 us) --
+    and 15 % for the long launch: the rolling passes of a long eager launch run on a forked stream, and that branch is NOT captured,
+    because the runtime replays the two branches of such a graph serially (measured 420 vs 253 us; rl_ptg_amd/csrc/ptg_env.hip,
+    launch_refresher), so the captured launch runs with its head pass only (+ 8 % in the A/B runs of profiles/r03_refresh_ab.txt).
+    (The second replay re-runs the captured step counts on the advanced state: fine for a stopwatch, and why the values are compared
+    after the first one.)"""
     import torch
     from rl_ptg_amd.engine import HipEngine
     from rl_ptg_amd.prep import synthetic_spec
@@ -148,7 +155,7 @@ def test_captured_rollout_keeps_the_table_refresher(warm, Tg):
     spec, _ = synthetic_spec(scenario=1, operation="OP1", eps_len_d=32)
     n = 65536
     dev = torch.device("cuda", 0)
-    acts = sticky_actions_device(warm + Tg, n, seed=77, device=dev, p_switch=1.0 / 12.0)
+    acts = sticky_actions_device(warm + 2 * Tg, n, seed=77, device=dev, p_switch=1.0 / 12.0)
     filler = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     res = {}
     for mode in ("eager", "graph"):
@@ -161,6 +168,8 @@ def test_captured_rollout_keeps_the_table_refresher(warm, Tg):
         if warm:
             eng.rollout(acts[:warm], obs[:warm], rew[:warm], done[:warm])
         eng.sync()
+        obs.zero_()
+        torch.cuda.synchronize()
         assert eng.rollout_launches(Tg) == 1
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g = None
@@ -170,25 +179,31 @@ def test_captured_rollout_keeps_the_table_refresher(warm, Tg):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(g, stream=side):
-                    eng.rollout(acts[warm:], obs, rew, done)
+                    eng.rollout(acts[warm:warm + Tg], obs, rew, done)
             torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            assert float(obs.abs().sum()) == 0.0               # captured, not run
+            g.replay()
+        else:
+            eng.rollout(acts[warm:warm + Tg], obs, rew, done)
+        eng.sync()
         torch.cuda.synchronize()
+        first = (obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), eng.get_state("i"), eng.get_state("cum_rew"))
         for _ in range(3):
             filler.zero_()                                      # ~0.6 ms of work ahead of the timed interval (longer than any host launch path; 3 GB through the caches)
         ev0.record()
         if g is not None:
             g.replay()
         else:
-            eng.rollout(acts[warm:], obs, rew, done)
+            eng.rollout(acts[warm + Tg:], obs, rew, done)
         ev1.record()
-        eng.sync()
         torch.cuda.synchronize()
-        res[mode] = (ev0.elapsed_time(ev1) * 1e3, obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), eng.get_state("i"), eng.get_state("cum_rew"))
+        res[mode] = (ev0.elapsed_time(ev1) * 1e3,) + first
         eng.close()
     t_e, t_g = res["eager"][0], res["graph"][0]
     for a, b in zip(res["eager"][1:], res["graph"][1:]):
         assert np.array_equal(a, b)
-    assert t_g <= 1.10 * t_e + 2.0, (t_e, t_g)
+    assert t_g <= (1.10 * t_e + 8.0 if Tg <= 20 else 1.15 * t_e), (t_e, t_g)
 
 
 def test_two_handles_on_two_streams_at_once():

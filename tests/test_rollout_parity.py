@@ -128,30 +128,49 @@ def test_config2_hot_kernels_vs_oracle_n4096(out_dtype, layout):
     eng.close(); ora.close()
 
 
-@pytest.mark.parametrize("out_dtype", ["float32", "float64"])
-def test_config3_slice_vs_oracle_n65536(out_dtype):
-    """BASELINE.json configs[2] at full size: N = 65 536, BS1/OP1, one workgroup per CU.  The oracle follows a 256-env slice (envs
-    are independent: the slice's tapes fed to a 256-env oracle) for 240 steps of the fused rollout from reset -- across the
-    refresher's rolling phase and several launch segments."""
-    n, K, L = 65536, 240, 256
-    lo, m = 40960 + 128, 256                                 # a slice that straddles two workgroups
-    spec, eng = _synthetic(n, 1, "OP1", out_dtype, "row")
+@pytest.mark.parametrize("n,scenario,operation,noise,out_dtype", [
+    (65536, 1, "OP1", "tape", "float32"), (65536, 1, "OP1", "tape", "float64"),
+    (65536, 1, "OP1", "rng", "float32"),               # bench.py's exact instantiation (in-kernel counter RNG) at full size
+    (262144, 3, "OP2", "tape", "float32"),             # BASELINE.json configs[3]: the CHP / EEG reward path (:291-293), 4 launches per step segment
+    (262144, 3, "OP2", "rng", "float64")])
+def test_full_size_slice_vs_oracle(n, scenario, operation, noise, out_dtype):
+    """BASELINE.json configs[2] (N = 65 536, BS1/OP1) and configs[3] (N = 262 144, BS3/OP2) at FULL size.  The oracle follows a
+    256-env slice that straddles two workgroups (envs are independent: the slice's action and noise tapes fed to a 256-env oracle) for
+    240 fused steps from reset -- across the refresher's rolling phase, several launch segments and (262 144) all four env slices of
+    a step segment.  noise = "rng": the kernels draw the state-change noise inline (what bench.py times); the oracle's tape then
+    comes from ptg_fill_noise_tape on a 256-env twin at the slice's global env offset -- the same counter streams
+    (include/ptg_env.h, ptg_set_noise_rng)."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.synthetic import sticky_actions_device
+    K, L, CH = 240, 256, 60
+    lo, m = (n // 8) * 5 + 128, 256                          # 40 960 + 128 at 65 536 envs; inside the third env slice at 262 144
+    spec, eng = _synthetic(n, scenario, operation, out_dtype, "row")
     rtol, atol = (RTOL64, ATOL64) if out_dtype == "float64" else (RTOL32, ATOL32)
-    eng.fill_noise_tape(seed=31, per_env_len=L)
-    tape = eng.get_noise_tape(L)
-    ora = _oracle(spec, m, tape[lo:lo + m])
+    if noise == "tape":
+        eng.fill_noise_tape(seed=31, per_env_len=L)
+        tape = eng.get_noise_tape(L)[lo:lo + m]
+    else:
+        eng.set_noise_rng(seed=31)
+        twin = HipEngine(spec.consts, spec.tables, spec.markets, m, device=0, out_dtype=out_dtype, obs_layout="row")
+        twin.set_global_env_offset(lo)
+        twin.fill_noise_tape(seed=31, per_env_len=L)
+        tape = twin.get_noise_tape(L)
+        twin.close()
+    ora = _oracle(spec, m, tape)
     ora.reset()
     eng.reset()
-    import torch
-    from rl_ptg_amd.synthetic import sticky_actions_device
     acts = sticky_actions_device(K, n, seed=3, device=torch.device("cuda", 0))
     a_host = acts[:, lo:lo + m].cpu().numpy()
-    o, r, d = eng.rollout(acts[:100])
-    o2, r2, d2 = eng.rollout(acts[100:])
-    eng.sync()
-    o = torch.cat([o, o2])[:, lo:lo + m].cpu().numpy()
-    r = torch.cat([r, r2])[:, lo:lo + m].cpu().numpy()
-    assert int(d.sum()) + int(d2.sum()) == 0
+    o_parts, r_parts, n_done = [], [], 0
+    for t0 in range(0, K, CH):                               # 60 steps per call: 2.2 GB (float32) of observations at 262 144 envs
+        o, r, d = eng.rollout(acts[t0:t0 + CH])
+        eng.sync()
+        o_parts.append(o[:, lo:lo + m].cpu().numpy()); r_parts.append(r[:, lo:lo + m].cpu().numpy())
+        n_done += int(d.sum())
+        del o, r, d
+    o, r = np.concatenate(o_parts), np.concatenate(r_parts)
+    assert n_done == 0
     for t in range(K):
         o_ref, r_ref, d_ref, _, _ = ora.step(a_host[t])
         np.testing.assert_allclose(o[t], o_ref, rtol=rtol, atol=atol, err_msg=f"step {t}")
@@ -160,4 +179,6 @@ def test_config3_slice_vs_oracle_n65536(out_dtype):
     for col, name in enumerate(INT_FIELDS):
         assert np.array_equal(eng.get_state(name)[lo:lo + m], ints[:, col]), name
     np.testing.assert_allclose(eng.get_state("cum_rew")[lo:lo + m], f64s[:, 1], rtol=1e-11, atol=1e-9)
+    assert len(np.unique(ints[:, 0])) >= 4                   # the slice went through (nearly) every METH_STATUS
+    assert int(eng.get_state("noise_count")[lo:lo + m].max()) <= L
     eng.close(); ora.close()

@@ -174,3 +174,88 @@ def test_create_destroy_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) < (32 << 20), (free0, free1)
+
+
+@pytest.mark.parametrize("n,layout,dtype", [(6, "row", "float64"), (4096, "row", "float32"), (4096, "feature", "float64"), (333, "row", "float32")])
+def test_host_step_phases_and_status_section(n, layout, dtype):
+    """ptg_step_host_begin / _tail / _end (include/ptg_env.h) through raw ctypes, as a C caller would drive them: after `tail` the rewards,
+    done flags and the contiguous METH_STATUS bytes are in the block, after `end` the observations; the three phases produce what the
+    one-call ptg_step_host produces on a twin handle (zero-copy route at n = 6, staged route above), and the status bytes equal the
+    METH_STATUS column of the returned rows.  Calling the phases out of order is PTG_E_INVALID, not UB."""
+    import ctypes as C
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    spec = _spec()
+    outs = []
+    for phased in (True, False):
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=dtype, obs_layout=layout)
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        eng.set_noise_rng(4)
+        eng.reset()
+        L, h = eng._L, eng._h
+        o_rew, o_done, o_stat, total = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        assert L.ptg_host_layout_ex(h, C.byref(o_rew), C.byref(o_done), C.byref(o_stat), C.byref(total)) == 0
+        t3 = C.c_size_t()
+        assert L.ptg_host_layout(h, None, None, C.byref(t3)) == 0 and t3.value == total.value      # the old call reports the same block size
+        assert o_rew.value % 16 == 0 and o_done.value % 16 == 0 and o_stat.value % 16 == 0 and total.value >= o_stat.value + n
+        blk = torch.empty(total.value, dtype=torch.uint8, pin_memory=True)
+        act = torch.empty(n, dtype=torch.int32, pin_memory=True)
+        fin = torch.empty(n * eng.obs_dim * (8 if dtype == "float64" else 4), dtype=torch.uint8, pin_memory=True)
+        nd = C.c_int(-1)
+        if phased:
+            assert L.ptg_step_host_tail(h, C.byref(nd)) == -1 and L.ptg_step_host_end(h) == -1          # nothing in flight: PTG_E_INVALID
+        rng = np.random.default_rng(9)
+        rows = []
+        for t in range(25):
+            act.numpy()[:] = rng.integers(0, 5, n)
+            args = (h, C.c_void_p(act.data_ptr()), 0, C.c_void_p(blk.data_ptr()), C.c_void_p(fin.data_ptr()), None)
+            if phased:
+                assert L.ptg_step_host_begin(*args, eng._stream()) == 0
+                assert L.ptg_step_host_begin(*args, eng._stream()) == -1                                # one host step at a time
+                assert L.ptg_step_host_tail(h, C.byref(nd)) == 0 and nd.value == 0
+                assert L.ptg_step_host_end(h) == 0
+            else:
+                assert L.ptg_step_host(*args, C.byref(nd), eng._stream()) == 0 and nd.value == 0
+            b = blk.numpy()
+            npdt = np.float64 if dtype == "float64" else np.float32
+            flat = b[:n * eng.obs_dim * np.dtype(npdt).itemsize].view(npdt)
+            mat = flat.reshape(eng.obs_dim, n).T if layout == "feature" else flat.reshape(n, eng.obs_dim)
+            status = b[o_stat.value:o_stat.value + n]
+            assert np.array_equal(status.astype(np.int64), np.rint(mat[:, eng.obs_dim - 9]).astype(np.int64)), t
+            rows.append(b[:o_stat.value + n].copy())
+        assert len({int(x) for r in rows for x in np.unique(r[o_stat.value:o_stat.value + n])}) >= 3    # several METH_STATUS values occurred
+        outs.append(rows)
+        eng.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_copy_obs_switch_and_layout_guard():
+    """copy_obs=True on a large batch: fresh arrays and a NEW infos list every step (DummyVecEnv semantics, ADVICE r2);
+    copy_obs=False: ring views and one persistent list; layouts whose columns are not the Dict observation's raise at once."""
+    from rl_ptg_amd.vec_env import PtGVecEnv
+    spec = _spec()
+    n = 2048
+    with pytest.raises(ValueError):
+        PtGVecEnv(spec, n, obs_layout="split", noise="device")
+    with pytest.raises(ValueError):
+        PtGVecEnv(spec, n, obs_layout="sb3_flat", noise="device")
+    rng = np.random.default_rng(2)
+    acts = [rng.integers(0, 5, n) for _ in range(8)]
+    res = {}
+    for copy in (True, False):
+        env = PtGVecEnv(spec, n, seed=1, out_dtype="float32", noise="device", copy_obs=copy)
+        env.reset()
+        kept = [env.step(a) for a in acts]
+        res[copy] = [({k: v.copy() for k, v in o.items()}, r.copy()) for o, r, d, i in kept]
+        if copy:
+            assert len({id(i) for _, _, _, i in kept}) == len(kept)                                      # a new list object per step
+            assert all(np.array_equal(kept[0][0][k], res[True][0][0][k]) for k in kept[0][0])            # step 0's arrays untouched 7 steps later
+        else:
+            assert len({id(i) for _, _, _, i in kept}) == 1
+        env.close()
+    # the last OBS_RING - 1 steps of the view route are still intact and equal the copies
+    for t in range(len(acts) - 3, len(acts)):
+        assert np.array_equal(res[True][t][1], res[False][t][1])
+        for k in res[True][t][0]:
+            assert np.array_equal(res[True][t][0][k], res[False][t][0][k]), (t, k)
