@@ -102,7 +102,7 @@ try:
               "profiler attached the event pair reads 4-7 us MORE than the dispatch duration above (tools/tsweep.py under rocprofv3: 10.5-15.9 vs 6.5-7.2 us at",
               "T = 1, 37-40 vs 33-37 at T = 20), without it the events match these dispatch durations (6.3-6.6 us at T = 1, 33-35 at T = 20); (ii) the whole",
               "profiled process runs 8-10 % slower than an un-profiled one (steady state 1.60-1.65 vs 1.47-1.53 us per step; MI355X_MICROARCH.md, DVFS",
-              "give-back item 2: never compare a profiled arm with an un-profiled one).  The un-profiled driver-argument run is profiles/r02_bench_driver_args.json."]
+              "give-back item 2: never compare a profiled arm with an un-profiled one).  The un-profiled driver-argument run is profiles/r03_bench_driver_args.json."]
     for nme, r in legs:
         lines.append(f"* {nme}: avg_launch_us = {r['avg_launch_us']:.2f} over {r['launches_timed']} launch(es), frac = {r['frac']:.3f}" +
                      (f" (kernel only {r['kernel_only_us']:.2f} us, refresher beside it {r['refresh_us']:.2f} us)" if "kernel_only_us" in r else ""))
