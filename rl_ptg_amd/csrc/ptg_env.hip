@@ -2457,7 +2457,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
                 }
             }
             if (!launched) { if (ll) PTG_PC(true); else PTG_PC(false); }
-            g_helper0 = g_helper1 = nullptr;
+            if (g_helper0) { h->prof_free.push_back({g_helper0, g_helper1}); g_helper0 = g_helper1 = nullptr; }      // (a helper nobody's record took: back to the pool)
             join_refresher(h, st, rp);
 #undef PTG_PC
 #undef PTG_PC2
