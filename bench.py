@@ -278,11 +278,7 @@ def main():
         # collective sits behind it), so the answer is agreed on OUTSIDE the clock.  Without a boundary nothing can have finished:
         # no query, no collective (the all-gather belongs to episode boundaries, not to the step path).
         s_end = eng.steps_to_episode_end()
-        boundary = s_end == 0 or s_end <= K
-        if multi:
-            flag = torch.tensor([1.0 if boundary else 0.0], dtype=torch.float64, device=coll_device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            boundary = bool(flag.item() > 0)
+        boundary = ptg_dist.episode_boundary_in_window(s_end, K, device=coll_device)
         # the slices the timed calls take are made before the clock starts (harness work, not the env's)
         if path == "rollout":
             timed_args = (actions[W:W + K], bufs[0][:K], bufs[1][:K], bufs[2][:K])

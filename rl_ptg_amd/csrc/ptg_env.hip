@@ -1952,6 +1952,7 @@ struct ptg_env {
     size_t vn_partials_cap = 0; int vn_T_cap = 0;
     double vn_gamma = 0.99, vn_eps = 1e-8, vn_clip = 10.0;
     bool fin_maybe = false;      // a generic step ran since the last ptg_finished_episodes: only those can finish episodes
+    void* fin_stage = nullptr; size_t fin_stage_bytes = 0;      // pinned staging of ptg_finished_episodes
     unsigned long long fin_dropped = 0;      // finished episodes never handed out: ring overflow, or a query whose cap was too small
     int tape_len = 0;
     double *d_pot_raw = nullptr, *d_pf_raw = nullptr;
@@ -2603,6 +2604,7 @@ void ptg_destroy(ptg_env* env)
     if (env->vn_den) (void)hipFree(env->vn_den);
     if (env->vn_moments) (void)hipFree(env->vn_moments);
     if (env->err_host) (void)hipHostFree(env->err_host);
+    if (env->fin_stage) (void)hipHostFree(env->fin_stage);
     for (void* q : {env->hs_act, env->hs_out, env->hs_final, (void*)env->hs_info}) if (q) (void)hipFree(q);
     for (auto& r : env->prof_used)
         for (hipEvent_t e : {r.e0, r.e1, r.h0, r.h1}) if (e) (void)hipEventDestroy(e);
@@ -2772,6 +2774,11 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
             hipHostGetDevicePointer(&dp, h->err_host, 0) != hipSuccess) { set_err(h, PTG_E_HIP, "hipHostMalloc of the error words failed"); return fail(PTG_E_HIP); }
         h->err_host[0] = 0; h->err_host[1] = 0;
         P.err = (int*)dp;
+    }
+    {   // pinned staging of ptg_finished_episodes, sized for the whole ring (allocated here: a first query pays no hipHostMalloc)
+        const size_t need = (size_t)P.fin_cap * (sizeof(double) + 2 * sizeof(int));
+        if (hipHostMalloc(&h->fin_stage, need, hipHostMallocDefault) == hipSuccess) h->fin_stage_bytes = need;
+        else { (void)hipGetLastError(); h->fin_stage = nullptr; }
     }
     if (hipMemset(P.fin_count, 0, sizeof(int)) != hipSuccess) {
         set_err(h, PTG_E_HIP, "hipMemset failed");
@@ -3567,21 +3574,37 @@ int ptg_finished_episodes(ptg_env* h, double* returns_host, int32_t* lengths_hos
     const int have = (int)std::min<unsigned>(total, (unsigned)h->P.fin_cap);
     const int n = std::min(have, cap);
     h->fin_dropped += (unsigned long long)(total - (unsigned)have) + (unsigned long long)(have - n);      // the list is cleared below either way
-    // entries [total - have, total) are live (ring); hand out the oldest n of them: at most two contiguous pieces
+    // entries [total - have, total) are live (ring); hand out the oldest n of them: at most two contiguous pieces.  All pieces go
+    // through ONE pinned staging block with asynchronous copies and one synchronise (three pageable hipMemcpy of 65 536 entries cost
+    // 230-250 us of the episode-boundary window; bench.py's episode_boundary.finished_query_us)
     if (n > 0) {
         const int cap_r = h->P.fin_cap, s0 = (int)((total - (unsigned)have) % (unsigned)cap_r);
         const int n0 = std::min(n, cap_r - s0), n1 = n - n0;
-        if (returns_host) {
-            HIP_TRY(h, hipMemcpy(returns_host, h->P.fin_ret + s0, sizeof(double) * n0, hipMemcpyDeviceToHost));
-            if (n1) HIP_TRY(h, hipMemcpy(returns_host + n0, h->P.fin_ret, sizeof(double) * n1, hipMemcpyDeviceToHost));
+        const size_t need = (size_t)n * (sizeof(double) + 2 * sizeof(int));
+        if (need > h->fin_stage_bytes) {
+            if (h->fin_stage) (void)hipHostFree(h->fin_stage);
+            h->fin_stage = nullptr; h->fin_stage_bytes = 0;
+            if (hipHostMalloc(&h->fin_stage, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->fin_stage = nullptr; }
+            else h->fin_stage_bytes = need;
         }
-        if (lengths_host) {
-            HIP_TRY(h, hipMemcpy(lengths_host, h->P.fin_len + s0, sizeof(int) * n0, hipMemcpyDeviceToHost));
-            if (n1) HIP_TRY(h, hipMemcpy(lengths_host + n0, h->P.fin_len, sizeof(int) * n1, hipMemcpyDeviceToHost));
-        }
-        if (env_ids_host) {
-            HIP_TRY(h, hipMemcpy(env_ids_host, h->P.fin_env + s0, sizeof(int) * n0, hipMemcpyDeviceToHost));
-            if (n1) HIP_TRY(h, hipMemcpy(env_ids_host + n0, h->P.fin_env, sizeof(int) * n1, hipMemcpyDeviceToHost));
+        char* stage = (char*)h->fin_stage;
+        double* s_ret = stage ? (double*)stage : returns_host;
+        int* s_len = stage ? (int*)(stage + (size_t)n * sizeof(double)) : lengths_host;
+        int* s_env = stage ? s_len + n : env_ids_host;
+        auto pull = [&](void* dst, const void* src0, const void* src_wrap, size_t el) -> hipError_t {
+            if (!dst) return hipSuccess;
+            hipError_t e = hipMemcpyAsync(dst, src0, el * n0, hipMemcpyDeviceToHost, nullptr);
+            if (e == hipSuccess && n1) e = hipMemcpyAsync((char*)dst + el * n0, src_wrap, el * n1, hipMemcpyDeviceToHost, nullptr);
+            return e;
+        };
+        if (returns_host) HIP_TRY(h, pull(s_ret, h->P.fin_ret + s0, h->P.fin_ret, sizeof(double)));
+        if (lengths_host) HIP_TRY(h, pull(s_len, h->P.fin_len + s0, h->P.fin_len, sizeof(int)));
+        if (env_ids_host) HIP_TRY(h, pull(s_env, h->P.fin_env + s0, h->P.fin_env, sizeof(int)));
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+        if (stage) {
+            if (returns_host) memcpy(returns_host, s_ret, sizeof(double) * n);
+            if (lengths_host) memcpy(lengths_host, s_len, sizeof(int) * n);
+            if (env_ids_host) memcpy(env_ids_host, s_env, sizeof(int) * n);
         }
     }
     HIP_TRY(h, hipMemset(h->P.fin_count, 0, sizeof(int)));

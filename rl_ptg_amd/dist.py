@@ -112,6 +112,21 @@ def all_gather_finished(returns, lengths, device=None, group=None):
     return np.concatenate(r_all), np.concatenate(l_all)
 
 
+def episode_boundary_in_window(steps_to_episode_end, n_steps, device=None, group=None):
+    """Does an episode end within the next `n_steps` vector steps on ANY rank?  `steps_to_episode_end` is this rank's
+    HipEngine.steps_to_episode_end() (0 = unknown to the host: a de-synchronised batch, where an episode may end on any step).  All
+    ranks get the same answer (one all-reduce of a flag when a process group is up), so the finished-episode all-gather behind it is
+    entered by everybody or by nobody.  SURVEY.md 8(e): the collective belongs to episode boundaries, not to the step path."""
+    mine = steps_to_episode_end == 0 or steps_to_episode_end <= n_steps
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(mine)
+    import torch
+    flag = torch.tensor([1.0 if mine else 0.0], dtype=torch.float64, device=torch.device("cpu") if device is None else torch.device(device))
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return bool(flag.item() > 0)
+
+
 def merge_moments(parts):
     """Chan merge of per-shard moments: parts [world, T, 3] of (count, mean, M2) -> [T, 3], shards taken in rank order
     (every rank computes the same floating-point result).  NumPy arrays or torch tensors."""

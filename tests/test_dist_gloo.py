@@ -34,6 +34,12 @@ def _worker(rank, world, port, q):
         ra2, la2 = ptg_dist.all_gather_finished(r2, l2)
         rz, lz = ptg_dist.all_gather_finished(np.zeros(0), np.zeros(0, np.int64))     # nobody finished anything
         assert len(rz) == 0 and len(lz) == 0
+        # the episode-boundary decision is the same on every rank: no rank has one (both far from the end), one rank's batch is
+        # de-synchronised (0 = unknown), one rank's episode ends inside the window
+        assert ptg_dist.episode_boundary_in_window(4000, 20) is False
+        assert ptg_dist.episode_boundary_in_window(0 if rank == 1 else 4000, 20) is True
+        assert ptg_dist.episode_boundary_in_window(15 if rank == 0 else 4000, 20) is True
+        assert ptg_dist.episode_boundary_in_window(21 if rank == 0 else 4000, 20) is False
         # reward-normalisation moments: rank r holds envs [r*5, r*5+3+2r) of a ragged split; merged = moments over all envs
         x = np.random.default_rng(42).normal(2.0, 3.0, (4, 8))[:, rank * 3:rank * 3 + 3 + 2 * rank]
         mom = np.stack([np.full(4, x.shape[1], float), x.mean(1), ((x - x.mean(1, keepdims=True)) ** 2).sum(1)], -1)
