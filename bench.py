@@ -220,7 +220,7 @@ def main():
     def measure(path, launch, layout, out_dtype, steady):
         """W warm-up steps, then exactly K timed steps of `path`.  Returns a dict: wall seconds, per-launch kernel times, ..."""
         torch.cuda.empty_cache()                              # each leg starts from a fresh allocator state (no recycled multi-GB blocks)
-        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=out_dtype, obs_layout=layout)
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=out_dtype, obs_layout=layout, obs_pitch="auto")
         F = eng.obs_dim
         configure(eng)
         if args.noise == "rng":
@@ -234,9 +234,9 @@ def main():
         bufs = None
         if path == "rollout":
             rows = max(K, W, STEADY_T if extra else 1)
-            oshape = (rows, F, n) if layout == "feature" else (rows, n, F)
-            # zero-filled once: every page of the output buffers has been written before the timed region
-            bufs = (torch.zeros(oshape, dtype=eng.out_dtype, device=device), torch.zeros((rows, n), dtype=eng.out_dtype, device=device),
+            # zero-filled once: every page of the output buffers has been written before the timed region.  (feature-major: [rows, F, N]
+            # views of [rows, F, pitch] storage when the engine chose a plane pitch, HipEngine obs_pitch="auto")
+            bufs = (eng.alloc_obs(rows, zero=True), torch.zeros((rows, n), dtype=eng.out_dtype, device=device),
                     torch.zeros((rows, n), dtype=torch.uint8, device=device))
 
         def run(t0, cnt):
@@ -333,7 +333,7 @@ def main():
             run(W + K, K)
             kernel_us, helper_us, launch_us = eng.profile_read_ex()
             eng.profile(False)
-        res = {"elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "kernel_us": kernel_us, "helper_us": helper_us, "n_launch": n_launch,
+        res = {"pitch": eng.pitch if layout == "feature" else None, "elapsed": elapsed, "span_ms": span_ms, "launch_us": launch_us, "kernel_us": kernel_us, "helper_us": helper_us, "n_launch": n_launch,
                "n_fin": len(r_all), "F": F, "steady": None, "rerun": graph is not None, "boundary": boundary, "steps_to_episode_end": s_end,
                "elapsed_rank": elapsed, "device_us_rank": float(np.sum(launch_us)) if launch_us is not None else span_ms * 1e3}
         if extra:                                             # steady state: two more 400-step launches, the second one counted
@@ -433,13 +433,12 @@ def main():
         kernel: termination, auto-reset over the episode plan, finished-episode compaction), the finished-episode query and the
         all-gather of the episodic returns over the ranks -- the one collective of the path, at the one place it belongs."""
         torch.cuda.empty_cache()
-        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout)
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=local_rank, out_dtype=args.out_dtype, obs_layout=args.obs_layout, obs_pitch="auto")
         configure(eng)
         eng.set_noise_rng(seed=20250614)
         F = eng.obs_dim
         acts = sticky_actions_device(chunk + B, n, seed=4321 + rank, device=device, p_switch=args.p_switch)
-        oshape = (chunk, F, n) if args.obs_layout == "feature" else (chunk, n, F)
-        bufs = (torch.zeros(oshape, dtype=eng.out_dtype, device=device), torch.zeros((chunk, n), dtype=eng.out_dtype, device=device),
+        bufs = (eng.alloc_obs(chunk, zero=True), torch.zeros((chunk, n), dtype=eng.out_dtype, device=device),
                 torch.zeros((chunk, n), dtype=torch.uint8, device=device))
         eng.reset()
         pre = eng.steps_to_episode_end() - B
@@ -506,7 +505,7 @@ def main():
             "config": {"workload": f"N={n} envs/GPU, {'BS1+BS2+BS3 mixed (env e -> scenario e % 3)' if args.mixed_scenarios else 'BS' + str(args.scenario)}/{args.operation}, synthetic 38-day trace (32-day episodes), "
                                    f"'mod' features, discrete sticky actions (p_switch={args.p_switch:.4f}), noise: {args.noise}",
                        "path": head["path"], "envs_per_gpu": n, "envs_total": n_total, "obs_dtype": args.out_dtype,
-                       "obs_dim": res["F"], "obs_layout": args.obs_layout, "parallelism": f"env-sharded x{world}, no per-step collective"},
+                       "obs_dim": res["F"], "obs_layout": args.obs_layout, "obs_plane_pitch": res.get("pitch"), "parallelism": f"env-sharded x{world}, no per-step collective"},
             "roofline": head["roofline"],
             "finished_episodes_gathered": int(res["n_fin"]),
         }

@@ -29,7 +29,7 @@ extern "C" {
 
 #define PTG_ABI_VERSION 4   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series;
                              * 4: + ptg_profile_read_ex, ptg_finished_dropped, ptg_host_buffers_changed, ptg_steps_to_episode_end,
-                             *    ptg_host_layout_ex (status section), ptg_step_host_begin / _tail / _end / _finish */
+                             *    ptg_host_layout_ex (status section), ptg_step_host_begin / _tail / _end / _finish, ptg_set_feature_pitch */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -156,6 +156,14 @@ int ptg_set_noise_tape(ptg_env* env, const double* tape_host, int per_env_len);
  * Both reset the per-env draw counters.  Statistically equivalent to, not bit-equal with, NumPy's Generator.normal. */
 int ptg_set_noise_rng(ptg_env* env, uint64_t seed);
 int ptg_fill_noise_tape(ptg_env* env, uint64_t seed, int per_env_len, void* stream);
+/* FEATURE_MAJOR outputs only: elements between two feature planes of the caller's observation buffers (obs_dev, final_obs_dev, the
+ * observation section of a host block; rollouts: [T][F][pitch]), n_envs <= pitch <= n_envs + 2^20; default n_envs (planes back to back).
+ * Element (t, q, e) lives at ((t * F + q) * pitch + e).  Why: with float64 outputs and a power-of-two batch the planes are 2^19 bytes
+ * apart and the 35 stores of a wave differ only above bit 19 -- measured 0.59 of the HBM peak; a pitch of n_envs + 128 elements
+ * (1 KiB) brings 0.70 (profiles/r03_fm_pitch.txt: pads of 256 B .. 130 KiB; 4 KiB and 64 KiB multiples do not help) for a consumer
+ * that can read a pitched matrix (torch: storage [F, pitch], view [:, :n_envs]).  float32 planes (2^18 bytes apart) do not need it.
+ * No reference counterpart (the reference has no batch dimension). */
+int ptg_set_feature_pitch(ptg_env* env, int64_t pitch_elems);
 /* global index of this handle's env 0 (multi-GPU shards): keys the RNG streams; default 0 */
 int ptg_set_global_env_offset(ptg_env* env, int64_t offset);
 int ptg_get_noise_tape(ptg_env* env, double* tape_host);          /* [n_envs][per_env_len] */

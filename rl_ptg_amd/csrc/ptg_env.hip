@@ -71,6 +71,7 @@ struct Regs {
 };
 
 struct DevParams {
+    int fm_pitch;                // feature-major outputs: elements between two feature planes (>= N; ptg_set_feature_pitch)
     int N, S, sim_step, eps_sim_steps, PA, F, mod, eps_len_d;
     int E, ep_stride;                      // eps_ind length (0 = eval env), pointer stride (mod E)
     int noise_inline, track_changes;       // draw noise from the counter RNG in the kernel; maintain StC.nchg (penalty != 0)
@@ -401,7 +402,7 @@ template <typename OUT, bool FM>
 struct ObsRow {
     OUT* p; size_t stride; const int* cmap; int q_stat; bool split;
     __device__ __forceinline__ ObsRow(OUT* base, const DevParams& P, int e)
-        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.N : 1), cmap(FM ? nullptr : P.cmap), q_stat(P.q_stat),
+        : p(base ? (FM ? base + e : base + (size_t)e * P.F) : nullptr), stride(FM ? (size_t)P.fm_pitch : 1), cmap(FM ? nullptr : P.cmap), q_stat(P.q_stat),
           split(!FM && P.split) {}
     // q = canonical column (the reference's observation order); SB3_FLAT rows hold the columns in sorted-key order with
     // METH_STATUS one-hot over 6 classes
@@ -825,6 +826,7 @@ struct RewC {                    // reward (:280-334) and normalisation (:206-21
 
 struct HotParams {
     int N, S, sim_step, eps_sim_steps, F, nT, tape_len, track_changes, flat;
+    int fm_pitch;                                     // feature-major outputs: elements between two feature planes (>= N; ptg_set_feature_pitch)
     int key_cold_max, key_hot_min, key_standby_max, n_hours, n_days, hstride, dstride;
     unsigned off_featB, off_gasn, off_euan, off_sc;   // element offsets into pool32 (featA at 0; sin/cos pairs at off_sc)
     unsigned off_gas, off_eua;                        // element offsets into pool64 (el at 0)
@@ -1079,7 +1081,7 @@ struct HotRow {                  // observation row addressing: uniform base + 3
     static constexpr unsigned B = sizeof(OUT);
     char* base; unsigned boff; unsigned qbytes; bool flat;
     __device__ __forceinline__ HotRow(OUT* b, const HotParams& P, int e)
-        : base((char*)b), boff(FM ? (unsigned)e * B : (unsigned)e * (unsigned)P.F * B), qbytes(FM ? (unsigned)P.N * B : B), flat(!FM && P.flat) {}
+        : base((char*)b), boff(FM ? (unsigned)e * B : (unsigned)e * (unsigned)P.F * B), qbytes(FM ? (unsigned)P.fm_pitch * B : B), flat(!FM && P.flat) {}
     __device__ __forceinline__ void put(int q, OUT v) const;
     // same address as (uniform pointer advanced by SALU) + (the one lane offset): no per-feature offset registers
     __device__ __forceinline__ void put_u(int q, OUT v) const;
@@ -1603,7 +1605,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         mkt_to_lds();
         hb_cur = hb4 >> 2; db_cur = db4 >> 2;
     }
-    const unsigned NF4 = (unsigned)P.N * (unsigned)P.F * B;
+    const unsigned NF4 = (unsigned)(FM ? P.fm_pitch : P.N) * (unsigned)P.F * B;      // bytes of one step's observation block
     char* obs_t = (char*)obs; char* rew_t = (char*)rew; char* done_t = (char*)done;      // consumer: rows of the step being finished
     double* info_t = info;
     // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
@@ -1772,7 +1774,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
 // VecEnv needs it as an int64 vector, and gathering column 26 of 65 536 rows of 140 bytes on the host costs more than the step.
 // c0 = the column that holds it (row / feature-major), or the first of its six one-hot columns (SB3_FLAT / SPLIT rows).
 template <typename OUT>
-__global__ void __launch_bounds__(256) k_pack_status(const OUT* __restrict__ obs, int N, int F, int c0, int fm, int onehot, uint8_t* __restrict__ status)
+__global__ void __launch_bounds__(256) k_pack_status(const OUT* __restrict__ obs, int N, int F, int c0, int fm, int onehot, uint8_t* __restrict__ status, int pitch)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
@@ -1781,7 +1783,7 @@ __global__ void __launch_bounds__(256) k_pack_status(const OUT* __restrict__ obs
         v = 0;
 #pragma unroll
         for (int j = 1; j < 6; j++) v += obs[(size_t)e * F + c0 + j] != (OUT)0 ? j : 0;
-    } else v = (int)(fm ? obs[(size_t)c0 * N + e] : obs[(size_t)e * F + c0]);
+    } else v = (int)(fm ? obs[(size_t)c0 * pitch + e] : obs[(size_t)e * F + c0]);
     status[e] = (uint8_t)v;
 }
 
@@ -2246,6 +2248,7 @@ HotParams make_hot_params(const ptg_env* h)
     const DevParams& P = h->P;
     HotParams F;
     memset(&F, 0, sizeof F);
+    F.fm_pitch = P.fm_pitch;
     F.N = P.N; F.S = P.S; F.sim_step = P.sim_step; F.eps_sim_steps = P.eps_sim_steps; F.F = P.F; F.nT = P.nT; F.tape_len = P.tape_len;
     F.flat = h->flat ? 1 : 0; F.track_changes = P.track_changes; F.key_cold_max = P.key_cold_max; F.key_hot_min = P.key_hot_min; F.key_standby_max = P.key_standby_max;
     F.n_hours = P.n_hours; F.n_days = P.n_days; F.hstride = P.hstride; F.dstride = P.dstride;
@@ -2267,11 +2270,14 @@ HotParams make_hot_params(const ptg_env* h)
     return F;
 }
 
+// elements of one step's observation block: F rows of N (row-major) or F planes of fm_pitch (feature-major)
+size_t obs_step_elems(const ptg_env* h) { return (size_t)h->F * (size_t)(h->fm ? h->P.fm_pitch : h->n); }
+
 // the hot kernels apply to a 13-hour look-ahead, a synchronised batch, and steps on which no env terminates
 bool hot_eligible(const ptg_env* h)
 {
     const unsigned long long osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
-    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && (unsigned long long)h->n * h->F * osz < 0xFFFFFFFFull;
+    return h->cfg.price_ahead == 13 && h->sync_k >= 0 && !h->knob_no_hot && (unsigned long long)obs_step_elems(h) * osz < 0xFFFFFFFFull;
 }
 
 int noise_mode(const ptg_env* h) { return h->P.tape_len > 0 ? NOISE_TAPE : (h->P.noise_inline ? NOISE_RNG : NOISE_NONE); }
@@ -2421,7 +2427,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
     for (int ts = 0; ts < T; ts += t_cap) {
         const int tn = std::min(t_cap, T - ts);
         const char* a_s = (const char*)actions + (size_t)ts * h->n * asz;
-        OUT* o_s = obs + (size_t)ts * h->n * h->F;
+        OUT* o_s = obs + (size_t)ts * obs_step_elems(h);
         OUT* r_s = rew + (size_t)ts * h->n;
         uint8_t* d_s = done + (size_t)ts * h->n;
         double* i_s = h->rollout_info ? h->rollout_info + (size_t)ts * h->n * PTG_N_INFO : nullptr;
@@ -2691,6 +2697,7 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         P.split = 1; P.q_stat = cfg->raw_modified ? 2 * cfg->price_ahead : cfg->price_ahead + 4;
         h->F = 16; h->split = true;
     }
+    P.fm_pitch = n_envs;
     P.N = n_envs; P.S = h->S; P.sim_step = cfg->sim_step; P.eps_sim_steps = cfg->eps_sim_steps; P.PA = cfg->price_ahead;
     P.F = h->F; P.mod = cfg->raw_modified; P.eps_len_d = cfg->eps_len_d; P.E = 0; P.ep_stride = 0; P.tape_len = 0;
     P.noise_inline = 0; P.noise_seed = 0; P.env_offset = 0; P.noise_sigma = cfg->noise;
@@ -2910,6 +2917,19 @@ int ptg_set_noise_rng(ptg_env* h, uint64_t seed)
     return 0;
 }
 
+int ptg_set_feature_pitch(ptg_env* h, int64_t pitch)
+{
+    if (!h) return PTG_E_INVALID;
+    if (!h->fm) return set_err(h, PTG_E_INVALID, "ptg_set_feature_pitch: the handle's obs_layout is not PTG_OBS_FEATURE_MAJOR");
+    if (pitch < h->n || pitch > (int64_t)h->n + (1 << 20)) return set_err(h, PTG_E_INVALID, "ptg_set_feature_pitch: pitch must be in [n_envs, n_envs + 2^20]");
+    if (h->hs.active) return set_err(h, PTG_E_INVALID, "ptg_set_feature_pitch: a host step is in flight");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    h->P.fm_pitch = (int)pitch;
+    for (void** q : {&h->hs_out, &h->hs_final}) if (*q) { (void)hipFree(*q); *q = nullptr; }      // staged host steps: sized by the old pitch
+    return 0;
+}
+
 int ptg_set_global_env_offset(ptg_env* h, int64_t offset)
 {
     if (!h || offset < 0) return set_err(h, PTG_E_INVALID, "bad env offset");
@@ -2995,7 +3015,7 @@ static int launch_rollout_generic(ptg_env* h, hipStream_t st, const void* action
     const size_t asz = action_kind == PTG_ACT_I64 ? 8 : 4, osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
     for (int t = 0; t < n_steps; t++) {
         const int rc = launch_step_generic(h, st, (const char*)actions_dev + (size_t)t * h->n * asz, action_kind,
-                                           (char*)obs_dev + (size_t)t * h->n * h->F * osz, (char*)rew_dev + (size_t)t * h->n * osz,
+                                           (char*)obs_dev + (size_t)t * obs_step_elems(h) * osz, (char*)rew_dev + (size_t)t * h->n * osz,
                                            done_dev + (size_t)t * h->n, nullptr, info_dev ? info_dev + (size_t)t * h->n * PTG_N_INFO : nullptr);
         if (rc) return rc;
     }
@@ -3043,7 +3063,7 @@ static int rollout_impl(ptg_env* h, const char* what, const void* actions_dev, i
     int t0 = 0;
     while (t0 < n_steps) {
         const char* a_t = (const char*)actions_dev + (size_t)t0 * h->n * asz;
-        char* o_t = (char*)obs_dev + (size_t)t0 * h->n * h->F * osz;
+        char* o_t = (char*)obs_dev + (size_t)t0 * obs_step_elems(h) * osz;
         char* r_t = (char*)rew_dev + (size_t)t0 * h->n * osz;
         uint8_t* d_t = done_dev + (size_t)t0 * h->n;
         double* i_t = info_dev ? info_dev + (size_t)t0 * h->n * PTG_N_INFO : nullptr;
@@ -3114,7 +3134,7 @@ int ptg_host_layout_ex(const ptg_env* h, size_t* off_rew, size_t* off_done, size
 {
     if (!h) return PTG_E_INVALID;
     const size_t osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4;
-    const size_t o_rew = ((size_t)h->n * h->F * osz + 15) / 16 * 16, o_done = (o_rew + (size_t)h->n * osz + 15) / 16 * 16;
+    const size_t o_rew = (obs_step_elems(h) * osz + 15) / 16 * 16, o_done = (o_rew + (size_t)h->n * osz + 15) / 16 * 16;
     const size_t o_status = (o_done + (size_t)h->n + 15) / 16 * 16;
     if (off_rew) *off_rew = o_rew;
     if (off_done) *off_done = o_done;
@@ -3162,7 +3182,7 @@ int ptg_step_host_begin(ptg_env* h, const void* actions_host, int action_kind, v
     const size_t osz = h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4, asz = action_kind == PTG_ACT_I64 ? 8 : 4;
     size_t o_rew, o_done, o_status, total;
     ptg_host_layout_ex(h, &o_rew, &o_done, &o_status, &total);
-    const size_t final_bytes = (size_t)h->n * h->F * osz, info_bytes = (size_t)h->n * PTG_N_INFO * sizeof(double);
+    const size_t final_bytes = obs_step_elems(h) * osz, info_bytes = (size_t)h->n * PTG_N_INFO * sizeof(double);
     // Small batches: the kernels read the actions from and write their outputs to the caller's pinned buffers directly (zero
     // copy: no DMA descriptors, one launch + one synchronise per step).  Large ones: device staging; the outputs come back as TWO
     // copies -- [rewards | done flags | status] (+ info rows) first, with an event behind them, then the observations -- so that the
@@ -3206,8 +3226,8 @@ int ptg_step_host_begin(ptg_env* h, const void* actions_host, int action_kind, v
         int c0, onehot;
         status_column(h, c0, onehot);
         const dim3 grid(grid_for(h->n, 256)), block(256);
-        if (osz == 8) hipLaunchKernelGGL(k_pack_status<double>, grid, block, 0, st, (const double*)d_out, h->n, h->F, c0, h->fm ? 1 : 0, onehot, (uint8_t*)(d_out + o_status));
-        else hipLaunchKernelGGL(k_pack_status<float>, grid, block, 0, st, (const float*)d_out, h->n, h->F, c0, h->fm ? 1 : 0, onehot, (uint8_t*)(d_out + o_status));
+        if (osz == 8) hipLaunchKernelGGL(k_pack_status<double>, grid, block, 0, st, (const double*)d_out, h->n, h->F, c0, h->fm ? 1 : 0, onehot, (uint8_t*)(d_out + o_status), h->P.fm_pitch);
+        else hipLaunchKernelGGL(k_pack_status<float>, grid, block, 0, st, (const float*)d_out, h->n, h->F, c0, h->fm ? 1 : 0, onehot, (uint8_t*)(d_out + o_status), h->P.fm_pitch);
         if ((rc = launch_check(h, "k_pack_status"))) return rc;
         HIP_TRY(h, hipMemcpyAsync((char*)out_host + o_rew, h->hs_out ? (char*)h->hs_out + o_rew : nullptr, total - o_rew, hipMemcpyDeviceToHost, st));
         if (info_host) HIP_TRY(h, hipMemcpyAsync(info_host, h->hs_info, info_bytes, hipMemcpyDeviceToHost, st));
@@ -3249,7 +3269,7 @@ int ptg_step_host_tail(ptg_env* h, int* n_done)
             for (int q = 0; q < h->n; q++) {
                 int v = 0;
                 if (onehot) { for (int j = 1; j < 6; j++) v += at((size_t)q * h->F + c0 + j) != 0.0 ? j : 0; }
-                else v = (int)(h->fm ? at((size_t)c0 * h->n + q) : at((size_t)q * h->F + c0));
+                else v = (int)(h->fm ? at((size_t)c0 * h->P.fm_pitch + q) : at((size_t)q * h->F + c0));
                 stt[q] = (uint8_t)v;
             }
         }
@@ -3271,7 +3291,7 @@ int ptg_step_host_end(ptg_env* h)
     if ((rc = wait_stream(h, hs.st))) return rc;
     if ((rc = check_error_flags(h))) return rc;
     if (hs.n_done && !hs.zc && hs.final_host) {                 // rare: the terminal observations of the episodes that just ended
-        const size_t final_bytes = (size_t)h->n * h->F * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);
+        const size_t final_bytes = obs_step_elems(h) * (h->cfg.out_dtype == PTG_OUT_F64 ? 8 : 4);
         HIP_TRY(h, hipMemcpyAsync(hs.final_host, h->hs_final, final_bytes, hipMemcpyDeviceToHost, hs.st));
         HIP_TRY(h, hipStreamSynchronize(hs.st));
     }

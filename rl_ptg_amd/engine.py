@@ -34,7 +34,11 @@ class PtgError(RuntimeError):
 
 
 class HipEngine:
-    def __init__(self, consts, tables, markets, n_envs, device=0, out_dtype="float32", obs_layout="row"):
+    def __init__(self, consts, tables, markets, n_envs, device=0, out_dtype="float32", obs_layout="row", obs_pitch=None):
+        """obs_pitch (obs_layout="feature" only): elements between two feature planes of the observation buffers -- None: n_envs (planes
+        back to back, `[F, N]` contiguous); an int >= n_envs; or "auto": n_envs + 1 KiB worth of elements for float64 outputs whose plane
+        stride would be a multiple of 64 KiB (power-of-two batches: planes 2^19 bytes apart run at 0.59 of the HBM peak, 0.70 with the
+        pitch; float32 planes do not need it and run slower with one -- profiles/r03_fm_pitch.txt; include/ptg_env.h ptg_set_feature_pitch).  With a pitch the observation tensors are `[F, N]` VIEWS of `[F, pitch]` storage."""
         import torch
         self._torch = torch
         self._L = _lib.lib()                      # raises if the extension is missing
@@ -83,17 +87,46 @@ class HipEngine:
             raise PtgError(rc, self._L.ptg_last_error(None).decode())
         self._h = h
         self.obs_dim = self._L.ptg_obs_dim(h)
+        osz = 8 if out_dtype == "float64" else 4
+        if obs_pitch == "auto":
+            import os
+            pad = int(os.environ.get("PTG_FM_PAD_BYTES", "1024"))         # (experiments: tools/r03_pitch2.sh -> profiles/r03_fm_pitch.txt)
+            obs_pitch = self.n + pad // osz if (self.feature_major and osz == 8 and pad and (self.n * osz) % 65536 == 0) else None
+        self.pitch = self.n if obs_pitch is None else int(obs_pitch)
+        if self.pitch != self.n:
+            if not self.feature_major:
+                raise ValueError("obs_pitch applies to obs_layout='feature' only")
+            self._chk(self._L.ptg_set_feature_pitch(h, self.pitch))
         self.action_type = int(c["action_type"])
         self.eval_mode = bool(c["train_or_eval"])
         with torch.cuda.device(self.device):
-            shape = (self.obs_dim, self.n) if self.feature_major else (self.n, self.obs_dim)
-            self.obs = torch.zeros(shape, dtype=self.out_dtype, device=self.device)
-            self.final_obs = torch.zeros(shape, dtype=self.out_dtype, device=self.device)
+            self.obs = self.alloc_obs(zero=True)
+            self.final_obs = self.alloc_obs(zero=True)
             self.rew = torch.zeros(self.n, dtype=self.out_dtype, device=self.device)
             self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
             self.info = torch.zeros((self.n, _lib.N_INFO), dtype=torch.float64, device=self.device) if self.eval_mode else None
 
     # ------------------------------------------------------------------ plumbing
+    def alloc_obs(self, T=None, zero=False):
+        """An observation buffer in this engine's layout: [N, F] row-major, [F, N] feature-major (a view of [F, pitch] storage when the
+        engine has a pitch); with T: [T, ...] for a rollout."""
+        torch = self._torch
+        make = torch.zeros if zero else torch.empty
+        lead = () if T is None else (int(T),)
+        if not self.feature_major:
+            return make(lead + (self.n, self.obs_dim), dtype=self.out_dtype, device=self.device)
+        t = make(lead + (self.obs_dim, self.pitch), dtype=self.out_dtype, device=self.device)
+        return t[..., :self.n] if self.pitch != self.n else t
+
+    def _check_obs(self, obs):
+        """a caller-supplied feature-major buffer must have the engine's plane pitch (and a contiguous env axis)"""
+        if self.feature_major:
+            ok = obs.stride(-1) == 1 and obs.stride(-2) == self.pitch and (obs.dim() == 2 or obs.stride(0) == self.obs_dim * self.pitch)
+        else:
+            ok = obs.is_contiguous()
+        if not ok:
+            raise ValueError(f"observation buffer strides {tuple(obs.stride())} do not match the engine's layout (pitch {self.pitch}); use alloc_obs()")
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.ptg_destroy(self._h)
@@ -196,6 +229,10 @@ class HipEngine:
         """Enqueue one vector step on the current stream; returns (obs, rew, done) device tensors (no sync)."""
         a = self.as_device_actions(actions)
         assert a.numel() == self.n
+        if obs is not None:
+            self._check_obs(obs)
+        if final_obs is not None:
+            self._check_obs(final_obs)
         obs = self.obs if obs is None else obs
         rew = self.rew if rew is None else rew
         done = self.done if done is None else done
@@ -215,8 +252,9 @@ class HipEngine:
         T = a.shape[0]
         with torch.cuda.device(self.device):
             if obs is None:
-                shape = (T, self.obs_dim, self.n) if self.feature_major else (T, self.n, self.obs_dim)
-                obs = torch.empty(shape, dtype=self.out_dtype, device=self.device)
+                obs = self.alloc_obs(T)
+            else:
+                self._check_obs(obs)
             if rew is None:
                 rew = torch.empty((T, self.n), dtype=self.out_dtype, device=self.device)
             if done is None:
@@ -234,8 +272,7 @@ class HipEngine:
         assert a.dim() == 2 and a.shape[1] == self.n
         T = a.shape[0]
         with torch.cuda.device(self.device):
-            shape = (T, self.obs_dim, self.n) if self.feature_major else (T, self.n, self.obs_dim)
-            obs = torch.empty(shape, dtype=self.out_dtype, device=self.device)
+            obs = self.alloc_obs(T)
             rew = torch.empty((T, self.n), dtype=self.out_dtype, device=self.device)
             done = torch.empty((T, self.n), dtype=torch.uint8, device=self.device)
             info = torch.empty((T, self.n, 24), dtype=torch.float64, device=self.device)

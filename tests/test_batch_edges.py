@@ -298,3 +298,49 @@ def test_api_misuse_returns_error_codes():
     eng.sync()
     assert np.isfinite(o.cpu().numpy()).all() and int(eng.get_state("k")[0]) == 4
     eng.close()
+
+
+@pytest.mark.parametrize("out_dtype", ["float32", "float64"])
+def test_feature_major_plane_pitch(out_dtype):
+    """ptg_set_feature_pitch (HipEngine obs_pitch): feature planes `pitch` elements apart -- the [F, N] view of [F, pitch] storage holds
+    what the back-to-back layout holds, bit for bit: reset rows, per-step launches (hot and generic kernel, incl. a terminating step with
+    its terminal observations) and fused rollouts; the padding between the planes is never written."""
+    import torch
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import synthetic_spec
+    spec, _ = synthetic_spec(scenario=2, operation="OP2", eps_len_d=1, train_steps=200000)      # 139-step episodes: a termination inside
+    n, Tn = 1000, 160
+    dev = torch.device("cuda", 0)
+    acts = torch.from_numpy(np.random.default_rng(3).integers(0, 5, (Tn, n)).astype(np.int32)).to(dev)
+    outs = {}
+    for pitch in (None, n + 24):
+        eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=out_dtype, obs_layout="feature", obs_pitch=pitch)
+        assert eng.pitch == (n if pitch is None else pitch)
+        eng.set_episode_plan(spec.eps_ind, n, n)
+        eng.set_noise_rng(8)
+        o0 = eng.reset().clone()
+        store = torch.full((Tn, eng.obs_dim, eng.pitch), -7.0, dtype=eng.out_dtype, device=dev)
+        obs = store[:, :, :n]
+        o_s, r_s, d_s = [], [], []
+        for t in range(20):                                              # hot per-step launches into rows of the pitched rollout buffer
+            o, r, d = eng.step(acts[t], obs=obs[t])
+            o_s.append(o.clone()); r_s.append(r.clone())
+        o_r, r_r, d_r = eng.rollout(acts[20:], obs[20:])                  # fused, across the terminating step at 139 (generic kernel + reset rows)
+        eng.sync()
+        assert int(d_r.sum()) == n
+        if eng.pitch != n:
+            assert bool((store[:, :, n:] == -7.0).all())                  # the padding stays untouched
+            with pytest.raises(ValueError):
+                eng.rollout(acts[:4], torch.empty((4, eng.obs_dim, n), dtype=eng.out_dtype, device=dev))      # a back-to-back buffer no longer fits
+        outs[pitch] = (o0.cpu().numpy(), torch.stack(o_s).cpu().numpy(), torch.stack(r_s).cpu().numpy(), o_r.cpu().numpy(), r_r.cpu().numpy(),
+                       eng.final_obs.cpu().numpy().copy(), eng.get_state("i"), eng.get_state("cum_rew"))
+        eng.close()
+    for a, b in zip(outs[None], outs[n + 24]):
+        assert np.array_equal(a, b)
+    # "auto": a pitch only where the plane stride would be a multiple of 64 KiB
+    e1 = HipEngine(spec.consts, spec.tables, spec.markets, 16384, device=0, out_dtype="float64", obs_layout="feature", obs_pitch="auto")
+    e2 = HipEngine(spec.consts, spec.tables, spec.markets, 1000, device=0, out_dtype="float64", obs_layout="feature", obs_pitch="auto")
+    assert e1.pitch == 16384 + 128 and e2.pitch == 1000
+    e1.close(); e2.close()
+    with pytest.raises(ValueError):
+        HipEngine(spec.consts, spec.tables, spec.markets, 64, device=0, obs_layout="row", obs_pitch=80)

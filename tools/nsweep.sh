@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/nsweep.sh > gpurun_out/nsweep.txt   -- bench.py over batch sizes / layouts / dtypes, one line each
-one() { timeout -k 10 400 python bench.py --no-cpu-baseline "$@" > gpurun_out/bench_sweep.log 2>&1; python - "$@" <<'PY'
+one() { timeout -k 10 400 python bench.py --no-cpu-baseline --no-boundary-leg "$@" > gpurun_out/bench_sweep.log 2>&1; python - "$@" <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open('gpurun_out/bench_sweep.log') if l.startswith('{')][-1])
@@ -23,6 +23,9 @@ one --envs 65536 --obs-layout feature --no-also
 one --envs 65536 --obs-layout sb3_flat --no-also
 one --envs 65536 --out-dtype float64 --no-also
 one --envs 65536 --out-dtype float64 --obs-layout feature --no-also
+one --envs 65536 --out-dtype float64 --obs-layout sb3_flat --no-also
+one --envs 65536 --obs-layout split --no-also
+one --envs 65536 --out-dtype float64 --obs-layout split --no-also
 one --envs 65536 --out-dtype float64 --path step --no-also
 one --envs 65536 --path step --launch eager --no-also
 one --envs 65536 --noise tape --no-also
