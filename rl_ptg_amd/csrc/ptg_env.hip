@@ -1611,7 +1611,10 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     // hand-off barrier: only the LDS traffic has to be complete.  __syncthreads() would also drain vmcnt -- the consumers'
     // stores and the gathers just issued -- once per step, which serialises exactly what this kernel overlaps
     auto handoff = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto produce = [&](const int it) {                      // state machine of step `it`
+#ifdef PTG_ABLATE_KEYLAG      // TIMING-ONLY ablation (wrong results): the state machine consumes the key gathered TWO steps ago (two registers used in
+    unsigned tkB = 0;         // turn), so the newest gather is never on the loop-carried chain: the upper bound of what any key run-ahead / speculation
+#endif                        // scheme could gain for chain-bound shapes (small batches, SPLIT rows); tools/r03_keylag.sh
+    auto produce_ = [&](const int it, unsigned& tk) {       // state machine of step `it`
         if (it > 0) R.flags = (R.flags & 0x1FFFFu) | (tk << 17);                  // Meth_T_cat = op[-1, 1] (:452)
         const int code = s_act[it * NP + lx];
         const int act = (code == 7) ? (int)((R.flags >> 12) & 7) : code;
@@ -1628,6 +1631,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
         slot[it & 1].w[lx] = (unsigned)ridx | ((R.flags & 7u) << 24) | (changed ? (1u << 27) : 0u) |
                              (((R.flags >> 12) & 7u) << 28) | (((R.flags >> 3) & 1u) << 31);       // + action, hot / cold: the info rows' fields
     };
+    auto produce = [&](const int it) { produce_(it, tk); };
     auto request = [&](const int t, rec_t& rec, unsigned& w) {                    // consumer: record gather of step t
         w = slot[t & 1].w[lx];
         rec = ld_off<rec_t>(rec_table(P, (const rec_t*)nullptr), (w & 0xFFFFFFu) * 64u);
@@ -1724,7 +1728,15 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     // made it drain the whole queue at the top of every consumer iteration).
     if (producer) {
         if (NOISE == NOISE_TAPE) z_next = P.tape[(size_t)((unsigned)R.nctr % (unsigned)P.tape_len) * P.N + e];
+#ifdef PTG_ABLATE_KEYLAG
+        {
+            int it = 0;
+            for (; it + 1 < T; it += 2) { produce_(it, tk); handoff(); produce_(it + 1, tkB); handoff(); }
+            if (it < T) { produce_(it, tk); handoff(); }
+        }
+#else
         for (int it = 0; it < T; it++) { produce(it); handoff(); if (it == 0) PTG_STAMP(4); if (it == 1) PTG_STAMP(5); }
+#endif
         PTG_STAMP(6);
         handoff();
     } else {
