@@ -38,6 +38,9 @@ for rep in range(4):
     print(f"rep {rep}: T = {T}; us since first entry, median over workgroups [min..max]")
     for role, rn in ((0, "producer"), (1, "consumer")):
         print("  " + rn + ": " + "  ".join(f"{names[q]} {np.median(rel[:, role, q]):.2f} [{rel[:, role, q].min():.2f}..{rel[:, role, q].max():.2f}]" for q in range(8)))
+    for role, rn in ((0, "producer"), (1, "consumer")):     # the XCDs' counters are offset against each other: differences inside a workgroup
+        d = (t[:, role, :] - t[:, role, 0:1]) / 100.0
+        print("  " + rn + " since own entry: " + "  ".join(f"{names[q]} +{np.median(d[:, q]):.2f}" for q in range(1, 8)))
     if rep == 3:
         ent = rel[:, 0, 0]
         print("  entry by blockIdx (every 8th = one XCD): " + " ".join("%.2f" % ent[b] for b in range(0, 256, 8)))
