@@ -27,9 +27,10 @@
 extern "C" {
 #endif
 
-#define PTG_ABI_VERSION 4   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series;
+#define PTG_ABI_VERSION 5   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series;
                              * 4: + ptg_profile_read_ex, ptg_finished_dropped, ptg_host_buffers_changed, ptg_steps_to_episode_end,
-                             *    ptg_host_layout_ex (status section), ptg_step_host_begin / _tail / _end / _finish, ptg_set_feature_pitch */
+                             *    ptg_host_layout_ex (status section), ptg_step_host_begin / _tail / _end / _finish, ptg_set_feature_pitch;
+                             * 5: + ptg_note_replays (the hot kernels read the step count from the device state: captured launches can be replayed) */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -227,6 +228,17 @@ int ptg_step_host_finish(ptg_env* env, int* n_done);      /* tail + end in one c
  * allocated / registered for as long as it is passed to ptg_step_host; a caller that frees one and later passes memory of another
  * kind at the same address calls this first (forgets the classifications). */
 int ptg_host_buffers_changed(ptg_env* env);
+/* hipGraph capture.  ptg_step / ptg_rollout enqueue kernels only (no synchronisation, no host round trip), so they can be captured on
+ * `stream` -- e.g. together with the policy's forward pass, whose ~10 launches per step otherwise bound a device-resident collect loop
+ * (profiles/r03_policy_loop.txt) -- and the captured launches can be REPLAYED: the hot kernels read the common step count from the device
+ * state.  Two things the host does for eager calls cannot happen inside a replay, so the caller does them:
+ *   * the one step per episode that terminates goes through another kernel: replay at most ptg_steps_to_episode_end() - 1 steps, then make
+ *     that step an eager call (a hot kernel that finds itself on the terminating step raises PTG_E_INVALID at the next synchronising call);
+ *   * ptg_note_replays(env, n): after replaying captured launches that together advanced the batch by n vector steps (the capture itself
+ *     counts as executed steps already), so that eager calls, ptg_steps_to_episode_end and ptg_rollout_launches stay in step.
+ * Buffers are the graph's (fixed addresses); kernel-flagged errors surface at the next ptg_sync / ptg_step_host / ptg_finished_episodes.
+ * No reference counterpart. */
+int ptg_note_replays(ptg_env* env, int n_steps);
 /* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
  * per-launch timing); negative PTG_E_* on a bad argument. */
 int ptg_rollout_launches(ptg_env* env, int n_steps);

@@ -1254,7 +1254,7 @@ __device__ unsigned long long g_stamps[256][2][8];
 // LAY: 0 row-major, 1 feature-major, 2 SB3_FLAT rows (the PTG_OBS_* values)
 template <int LAY, bool MOD, int NOISE, typename OUT>
 __global__ void __launch_bounds__(256)
-k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0, OUT* __restrict__ obs, OUT* __restrict__ rew,
+k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, OUT* __restrict__ obs, OUT* __restrict__ rew,
            uint8_t* __restrict__ done)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT, SPLIT = LAY == PTG_OBS_SPLIT;
@@ -1272,6 +1272,11 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, int k0
     ST_STAMP(1); ST_DRAIN(); ST_STAMP(2);
     HotRegs R;
     R.i = a.i; R.j = a.j; R.k = a.k; R.flags = a.flags; R.cum = b.cum; R.act_d = b.act_d; R.nctr = b.nctr;
+    // The common step count comes from the STATE, not from a kernel argument: a launch captured into a hipGraph (policy forward + this
+    // step, say) can be replayed step after step.  What a replay cannot do is route the one terminating step of an episode to the generic
+    // kernel -- the host does that for eager calls --, so a hot kernel that finds itself on that step raises the sequence flag (ptg_note_replays).
+    const int k0 = __builtin_amdgcn_readfirstlane(a.k);
+    if (k0 >= P.eps_sim_steps - 6) { if (threadIdx.x == 0) P.err[2] = 1; }
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const int act = hot_decode(actk, P, ri, rf, R.flags);
     HotLoads<OUT> Q;
@@ -1414,7 +1419,7 @@ __device__ __forceinline__ void pc_load_next(const HotParams& P, unsigned hb4, u
 
 template <int LAY, bool MOD, int NOISE, bool LDSLUT, bool FULL, typename OUT, bool INFO = false>
 __global__ void __launch_bounds__(512)
-k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int k0, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
+k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int T, OUT* __restrict__ obs, OUT* __restrict__ rew,
              uint8_t* __restrict__ done, const unsigned short* __restrict__ lut16, const unsigned short* __restrict__ rkey, int e_base, int vec_rows,
              double* __restrict__ info, int refresh_rec)
 {
@@ -1559,6 +1564,10 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
     }
     __syncthreads();
     PTG_STAMP(3);
+    // step count of the launch's first step: from the state (a captured launch can be replayed, see k_step_hot).  Read HERE, behind the
+    // prologue's barrier, where the state has long arrived: right behind its load the wait would hold up the staging loads (+0.5 us per launch)
+    const int k0 = __builtin_amdgcn_readfirstlane(R.k);
+    if (k0 + T > P.eps_sim_steps - 6) { if (threadIdx.x == 0) P.err[2] = 1; }      // the launch would run over the episode's terminating step
     const unsigned short* lut = LDSLUT ? s_lut : nullptr;
     const unsigned mset = (R.flags >> 15) & 3;
     // series offsets of step count k1 for this env (:442-447); uniform except for the episode offset
@@ -2308,9 +2317,9 @@ void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, 
     if (h->profiling) {
         hipEvent_t e0, e1;
         prof_pair(h, e0, e1);
-        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, h->sync_k, obs, rew, done);
+        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, obs, rew, done);
     } else
-        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, hp, actions, kind, h->sync_k, obs, rew, done);
+        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, hp, actions, kind, obs, rew, done);
 }
 
 }  // namespace ptg_hot
@@ -2460,10 +2469,10 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
             hipEvent_t pe0, pe1;                                                                                      \
             prof_pair(h, pe0, pe1);                                                                                   \
             prof_attach_helper(h);                                                                                    \
-            hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)sh, st, pe0, pe1, 0, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, \
+            hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)sh, st, pe0, pe1, 0, hp, (const void*)a_s, kind, tn, o_s, r_s, d_s, \
                                   (const unsigned short*)h->d_lut16, (const unsigned short*)h->d_rkey, e0, vec_rows, i_s, rr); \
         } else                                                                                                        \
-            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s, rr); \
+            hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s, rr); \
     } while (0)
 #define PTG_PC(LL) do { if (full) PTG_PC2(LL, true); else PTG_PC2(LL, false); } while (0)
             bool launched = false;
@@ -2471,7 +2480,7 @@ void launch_rollout_hot(ptg_env* h, hipStream_t st, const void* actions, int kin
                 if (i_s) {                                  // the eval info stream: one variant (lookup in global memory, any batch size)
                     auto kfn = k_rollout_pc<LAY, MOD, NOISE, false, false, double, true>;
                     lds_attr_once(h, (const void*)kfn, (int)lds_max);
-                    hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, k0, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s, rr);
+                    hipLaunchKernelGGL(kfn, grid, block, sh, st, hp, (const void*)a_s, kind, tn, o_s, r_s, d_s, h->d_lut16, h->d_rkey, e0, vec_rows, i_s, rr);
                     launched = true;
                 }
             }
@@ -2568,6 +2577,11 @@ int check_error_flags(ptg_env* h)          // after the stream has been synchron
     if (__atomic_load_n(&e[1], __ATOMIC_RELAXED)) {
         __atomic_exchange_n(&e[1], 0, __ATOMIC_RELAXED);
         return set_err(h, PTG_E_RANGE, "a price index left the market series (episode longer than the data)");
+    }
+    if (__atomic_load_n(&e[2], __ATOMIC_RELAXED)) {
+        __atomic_exchange_n(&e[2], 0, __ATOMIC_RELAXED);
+        return set_err(h, PTG_E_INVALID, "a hot step / rollout kernel ran on the terminating step of an episode: a captured launch was replayed "
+                       "past ptg_steps_to_episode_end (that step needs an eager call), or replays were not reported with ptg_note_replays");
     }
     return 0;
 }
@@ -2789,9 +2803,9 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         return fail(rc);
     {   // the error words live in pinned host memory the kernels can write (see DevParams::err)
         void* dp = nullptr;
-        if (hipHostMalloc((void**)&h->err_host, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        if (hipHostMalloc((void**)&h->err_host, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer(&dp, h->err_host, 0) != hipSuccess) { set_err(h, PTG_E_HIP, "hipHostMalloc of the error words failed"); return fail(PTG_E_HIP); }
-        h->err_host[0] = 0; h->err_host[1] = 0;
+        h->err_host[0] = 0; h->err_host[1] = 0; h->err_host[2] = 0; h->err_host[3] = 0;
         P.err = (int*)dp;
     }
     {   // pinned staging of ptg_finished_episodes, sized for the whole ring (allocated here: a first query pays no hipHostMalloc)
@@ -3132,6 +3146,20 @@ int ptg_rollout_launches(ptg_env* h, int n_steps)
         }
     }
     return launches;
+}
+
+// The hot kernels take the step count from the device state, so a captured ptg_step / ptg_rollout can be replayed; the host's own count
+// (which routes the terminating step of an episode to the generic kernel) only sees eager calls and the capture itself.
+int ptg_note_replays(ptg_env* h, int n_steps)
+{
+    if (!h || n_steps < 0) return set_err(h, PTG_E_INVALID, "ptg_note_replays: bad argument");
+    if (h->sync_k < 0) return set_err(h, PTG_E_INVALID, "ptg_note_replays: the batch is not synchronised (captured hot launches do not exist for it)");
+    const int k_term = h->cfg.eps_sim_steps - 6;
+    if (h->sync_k + n_steps > k_term)
+        return set_err(h, PTG_E_INVALID, "ptg_note_replays: %d replayed steps from step %d run over the terminating step %d of the episode",
+                       n_steps, h->sync_k, k_term);
+    h->sync_k += n_steps;
+    return 0;
 }
 
 int ptg_steps_to_episode_end(ptg_env* h, int* steps)

@@ -320,6 +320,12 @@ class HipEngine:
         self._chk(self._L.ptg_steps_to_episode_end(self._h, C.byref(s)))
         return int(s.value)
 
+    def note_replays(self, n_steps):
+        """Tell the handle that captured hot launches were REPLAYED for `n_steps` vector steps in all (include/ptg_env.h, "hipGraph
+        capture"): step() / rollout() captured into a graph can be replayed because the kernels read the step count from the device state;
+        the host-side count that routes an episode's terminating step only sees eager calls and the capture itself."""
+        self._chk(self._L.ptg_note_replays(self._h, int(n_steps)))
+
     def sync(self):
         self._chk(self._L.ptg_sync(self._h, self._stream()))
 

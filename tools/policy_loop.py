@@ -1,7 +1,8 @@
 """What the SB3-facing observation hand-off buys end to end: a collect loop  obs -> policy -> action -> env step  with a
 policy of the shape the reference trains (SB3 "MultiInputPolicy": CombinedExtractor's 40 columns -> 64 -> 64 -> 5 logits, tanh; random
-weights, greedy actions), three ways:
+weights, greedy actions), four ways:
   flat    PTG_OBS_SB3_FLAT rows stay on the device: torch MLP on the [N, 40] tensor the kernel wrote, ptg_step on the action tensor it produced
+  graph   the flat loop captured once (policy forward + ptg_step) and replayed as one hipGraph per step (ptg_note_replays afterwards)
   split   PTG_OBS_SPLIT rows (16 columns) + policy_split.FirstLayerSplit for the first layer
   host    the drop-in route of the reference's loop: PtGVecEnv.step(numpy actions) -> dict of NumPy arrays -> flattened on the host ->
           torch.as_tensor(...).cuda() -> policy -> actions.cpu().numpy()   (what SB3's collect_rollouts does around a VecEnv)
@@ -54,6 +55,30 @@ def step_flat(o):
     return eng.step(a, want_final=False)[0]
 dt = timed(step_flat, obs)
 print(f"flat   (device-resident, [N, 40] rows):            {dt * 1e6:8.1f} us per vector step = {n / dt:.3e} env-steps/s", flush=True)
+eng.close()
+
+# --- the same loop captured once (policy forward + ptg_step) and replayed as a hipGraph: the hot kernels read the step count from the state
+eng = engine("sb3_flat")
+obs_static = eng.reset()
+a_static = torch.zeros(n, dtype=torch.int32, device=dev)
+def body():
+    a_static.copy_(l3(torch.tanh(l2(torch.tanh(l1(obs_static))))).argmax(dim=1))
+    eng.step(a_static, want_final=False)                     # writes the next observations into obs_static (= eng.obs)
+with torch.no_grad():
+    for _ in range(3):
+        body()                                              # (torch wants the ops warm before a capture)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+dt = timed(lambda o: g.replay(), None)
+eng.note_replays(50 + K - 1)                                 # the capture counted as one step; every replay beyond the first is reported
+eng.sync()
+assert eng.steps_to_episode_end() == int(spec.consts["eps_sim_steps"]) - 5 - (3 + 50 + K)
+print(f"graph  (flat rows, policy + ptg_step as one hipGraph): {dt * 1e6:6.1f} us per vector step = {n / dt:.3e} env-steps/s", flush=True)
 eng.close()
 
 # --- split rows + first layer from projection tables
