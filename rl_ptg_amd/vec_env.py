@@ -304,10 +304,35 @@ class PtGVecEnv(_VecEnvBase):
         self.engine.sync()
         self._ep_start[:] = time.time()
         self._needs_reset = False
-        self.reset_infos = [{} for _ in range(self.num_envs)]
+        # DummyVecEnv.reset keeps what each env's reset() returned as info -- the reference returns _get_info() there (:504).  Built
+        # for batches of the reference's size; a 65 536-env batch gets empty dicts (nothing in SB3's loops reads them; 24 keys x N dicts)
+        self.reset_infos = self.reset_info_rows() if self.num_envs <= self.RESET_INFO_MAX_ENVS else [{} for _ in range(self.num_envs)]
         if self.norm_reward:                                  # VecNormalize.reset(): self.returns = np.zeros(self.num_envs)
             self.engine.vn_set(returns=np.zeros(self.num_envs))
         return self._obs_dict(obs)
+
+    RESET_INFO_MAX_ENVS = 256
+
+    def reset_info_rows(self, indices=None):
+        """_get_info() of freshly reset envs (env/ptg_gym_env.py:251-278 with the state of :105-138): zero revenue terms, the flows of the
+        single cooldown row the env starts in, the prices of its episode's first hour / day."""
+        eng, spec = self.engine, self.spec
+        st = {f: eng.get_state(f) for f in ("act_ep_d", "i", "meth_state", "current_action", "hot_cold", "T_cat", "market_set")}
+        cooldown = spec.tables["cooldown"]
+        rows = []
+        for e in (range(self.num_envs) if indices is None else indices):
+            m = spec.markets[int(st["market_set"][e])]
+            d = int(st["act_ep_d"][e])
+            row = cooldown[int(st["i"][e])]
+            rows.append({"step": 0, "el_price_act": float(m["el"][d * 24]), "gas_price_act": float(m["gas"][d]), "eua_price_act": float(m["eua"][d]),
+                         "Meth_State": int(st["meth_state"][e]), "Meth_Action": ACTIONS[int(st["current_action"][e])],
+                         "Meth_Hot_Cold": int(st["hot_cold"][e]), "Meth_T_cat": float(st["T_cat"][e]),
+                         "Meth_H2_flow": float(row[2]), "Meth_CH4_flow": float(row[3]), "Meth_H2O_flow": float(row[5]), "Meth_el_heating": float(row[6]),
+                         "ch4_revenues [ct/h]": 0.0, "steam_revenues [ct/h]": 0.0, "o2_revenues [ct/h]": 0.0, "eua_revenues [ct/h]": 0.0,
+                         "chp_revenues [ct/h]": 0.0, "elec_costs_heating [ct/h]": -0.0, "elec_costs_electrolyzer [ct/h]": -0.0,
+                         "water_costs [ct/h]": -0.0, "reward [ct]": 0.0, "cum_reward": 0, "Pot_Reward": float(m["pot_rew"][d * 24]),
+                         "Part_Full": float(m["part_full"][d * 24])})
+        return rows
 
     def step_async(self, actions):
         a = np.asarray(actions)
@@ -529,20 +554,7 @@ class PTGEnv:
         return obs, self._reset_info()
 
     def _reset_info(self):
-        """_get_info() of a freshly reset env (env/ptg_gym_env.py:251-278, :105-138): zero revenue terms, flows of the single
-        cooldown row the env starts in."""
-        eng, spec = self._vec.engine, self._vec.spec
-        m = spec.markets[0]
-        d = int(eng.get_state("act_ep_d")[0])
-        row = spec.tables["cooldown"][int(eng.get_state("i")[0])]
-        return {"step": 0, "el_price_act": float(m["el"][d * 24]), "gas_price_act": float(m["gas"][d]), "eua_price_act": float(m["eua"][d]),
-                "Meth_State": int(eng.get_state("meth_state")[0]), "Meth_Action": ACTIONS[int(eng.get_state("current_action")[0])],
-                "Meth_Hot_Cold": int(eng.get_state("hot_cold")[0]), "Meth_T_cat": float(eng.get_state("T_cat")[0]),
-                "Meth_H2_flow": float(row[2]), "Meth_CH4_flow": float(row[3]), "Meth_H2O_flow": float(row[5]), "Meth_el_heating": float(row[6]),
-                "ch4_revenues [ct/h]": 0.0, "steam_revenues [ct/h]": 0.0, "o2_revenues [ct/h]": 0.0, "eua_revenues [ct/h]": 0.0,
-                "chp_revenues [ct/h]": 0.0, "elec_costs_heating [ct/h]": -0.0, "elec_costs_electrolyzer [ct/h]": -0.0,
-                "water_costs [ct/h]": -0.0, "reward [ct]": 0.0, "cum_reward": 0, "Pot_Reward": float(m["pot_rew"][d * 24]),
-                "Part_Full": float(m["part_full"][d * 24])}
+        return self._vec.reset_info_rows([0])[0]
 
     def step(self, action):
         a = np.asarray(action).reshape(-1)[:1]

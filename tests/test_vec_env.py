@@ -30,6 +30,13 @@ def test_vec_env_matches_reference_stack(case):
     obs = env.reset()
     assert obs["METH_STATUS"].dtype == np.int64 and obs["T_CAT"].dtype == np.float64 and obs["T_CAT"].shape == (n, 1)
     np.testing.assert_allclose(_flat(obs, order), tr["reset_obs"], rtol=RTOL, atol=ATOL)
+    # DummyVecEnv.reset keeps each env's reset info: the reference returns _get_info() there (env/ptg_gym_env.py:504)
+    assert len(env.reset_infos) == n
+    for e in range(n):
+        assert list(env.reset_infos[e]) == list(INFO_KEYS)
+        for q, k in enumerate(INFO_KEYS):
+            if k != "Meth_Action":
+                assert float(env.reset_infos[e][k]) == tr["reset_info"][e, q], (e, k)
     K = tr["actions"].shape[0]
     n_post = 0
     ret = np.zeros(n)
