@@ -10,6 +10,10 @@ from collections import defaultdict
 tag = sys.argv[1]
 bench_args = sys.argv[2] if len(sys.argv) > 2 else "--gpus 1 --steps 20 --warmup 5"
 K = int(re.search(r"--steps (\d+)", bench_args).group(1)) if "--steps" in bench_args else 2000
+W = int(re.search(r"--warmup (\d+)", bench_args).group(1)) if "--warmup" in bench_args else 400
+# bench.py runs the W warm-up steps of a rollout leg as TWO launches (W // 2 steps, then the rest right before the clock) when W >= 2:
+# the timed launch is dispatch number NW of its kernel, the steady-state rollouts follow it
+NW = 2 if W >= 2 else 1
 os.makedirs("profiles", exist_ok=True)
 ours = ("k_step", "k_rollout", "k_reset", "k_build", "k_fill", "k_init", "k_zero", "k_extract", "k_refresh", "k_vn")
 LAY = {"0": "row", "1": "feature", "2": "sb3_flat", "3": "split"}
@@ -56,7 +60,7 @@ lines = [f"# rocprofv3 summary, {tag}", "",
          "in-kernel RNG).  bench.py runs four legs, each on a fresh handle: the headline `ptg_rollout` with row-major observations, `ptg_step`",
          "(K launches replayed as one hipGraph), `ptg_rollout` with feature-major observations and with float64 row-major observations (`<row,f64>`).",
          "Dispatches of `k_rollout_pc<row>` in trace order:",
-         f"the W-step warm-up launch from reset, THE TIMED {K}-step LAUNCH (bench.py's `roofline.avg_launch_us`), then the two 400-step",
+         f"the warm-up launch(es) from reset ({W} steps as {NW} launch(es)), THE TIMED {K}-step LAUNCH (bench.py's `roofline.avg_launch_us`), then the two 400-step",
          "steady-state rollouts (`steady_state`; 250 + 150 steps each); `k_rollout_pc<feature>`: warm-up, timed.  `k_refresh` is the table refresher's",
          "rolling-pass kernel (forked from the rollout's stream; only for launches long enough to need one, DESIGN.md section 5).  HBM counters: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the",
          "same command with `--launch eager`.  FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads); counter unit KiB.", "",
@@ -71,25 +75,25 @@ for k in sorted(trace):
     if k.startswith("k_rollout_pc"):
         d = [x[1] for x in sorted(trace[k])]
         lines.append(f"`{k}` dispatches in order [us]: " + ", ".join(f"{x / 1e3:.1f}" for x in d) +
-                     (f"  -> timed {K}-step launch: **{d[1] / 1e3:.1f} us** = {d[1] / 1e3 / K:.3f} us per step" if len(d) > 1 else "") +
-                     (f"; second 400-step steady rollout: {sum(d[2 + (len(d) - 2) // 2:]) / 1e3:.1f} us = {sum(d[2 + (len(d) - 2) // 2:]) / 1e3 / 400:.3f} us per step" if len(d) > 3 else ""))
+                     (f"  -> timed {K}-step launch: **{d[NW] / 1e3:.1f} us** = {d[NW] / 1e3 / K:.3f} us per step" if len(d) > NW else "") +
+                     (f"; second 400-step steady rollout: {sum(d[NW + 1 + (len(d) - NW - 1) // 2:]) / 1e3:.1f} us = {sum(d[NW + 1 + (len(d) - NW - 1) // 2:]) / 1e3 / 400:.3f} us per step" if len(d) > NW + 2 else ""))
 # start / end stamps of the headline launch and of every table-refresher dispatch near it (the interval bench.py reports
 # is the union of the two; since round 3 the pass at the head of a launch runs INSIDE the rollout kernel and no k_refresh precedes it)
 hk = "k_rollout_pc<row>"
-if hk in trace and len(trace[hk]) > 1:
+if hk in trace and len(trace[hk]) > NW:
     disp = sorted(trace[hk])
     refs = sorted(trace.get("k_refresh", []))
     lines += ["", f"Dispatch stamps around `{hk}` (ns, relative to the start of the timed {K}-step launch; from the kernel trace):", "",
               "| dispatch | start | end | duration us |", "|---|---|---|---|"]
-    t0 = disp[1][0]
-    for name, lst in (("k_rollout_pc<row> warm-up launch", disp[0:1]), (f"k_rollout_pc<row> TIMED {K}-step launch", disp[1:2]),
-                      ("k_rollout_pc<row> next launch (steady_state leg)", disp[2:3])):
+    t0 = disp[NW][0]
+    for name, lst in (("k_rollout_pc<row> warm-up launch", disp[0:NW]), (f"k_rollout_pc<row> TIMED {K}-step launch", disp[NW:NW + 1]),
+                      ("k_rollout_pc<row> next launch (steady_state leg)", disp[NW + 1:NW + 2])):
         for st, du in lst:
             lines.append(f"| {name} | {st - t0} | {st + du - t0} | {du / 1e3:.2f} |")
-    near = [(st, du) for st, du in refs if disp[0][0] - 50000 <= st <= (disp[2][0] + disp[2][1] if len(disp) > 2 else disp[1][0] + disp[1][1] + 50000)]
+    near = [(st, du) for st, du in refs if disp[0][0] - 50000 <= st <= (disp[NW + 1][0] + disp[NW + 1][1] if len(disp) > NW + 1 else disp[NW][0] + disp[NW][1] + 50000)]
     for st, du in near:
         lines.append(f"| k_refresh | {st - t0} | {st + du - t0} | {du / 1e3:.2f} |")
-    inside = [1 for st, du in refs if st + du > disp[1][0] - 20000 and st < disp[1][0] + disp[1][1]]
+    inside = [1 for st, du in refs if st + du > disp[NW][0] - 20000 and st < disp[NW][0] + disp[NW][1]]
     lines.append("")
     lines.append(f"k_refresh dispatches that end within 20 us before the timed launch or overlap it: **{len(inside)}**" +
                  (" (the head pass is inside the rollout kernel; rolling passes only in launches long enough to need one)" if not inside else ""))
@@ -123,14 +127,14 @@ for k in sorted(pmc):
         continue
     if layout.endswith(",f64"):
         layout, dt = layout[:-4], "float64"
-    if k.startswith("k_rollout_pc") and len(fs) > 1 and len(ws) > 1:
-        f, w_ = fs[1], ws[1]                                  # the timed launch (trace order: warm-up, timed, ...)
+    if k.startswith("k_rollout_pc") and len(fs) > NW and len(ws) > NW:
+        f, w_ = fs[NW], ws[NW]                                # the timed launch (trace order: warm-up launch(es), timed, ...)
         tot = 2 * f * 1024 + w_ * 1024
         lines.append(f"| {k} | timed {K}-step launch | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / K:.0f} B per step = {tot / K / 65536:.1f} B per env-step |")
         traffic[f"rollout_{layout}_{dt}"] = {"bytes_per_step": tot / K, "steps_in_measured_launch": K}
-        if len(fs) > 3 and len(ws) > 3 and len(fs) == len(ws):      # the two 400-step steady-state rollouts (each one or more launches): the second one
-            h2 = (len(fs) - 2) // 2
-            f, w_ = sum(fs[2 + h2:]), sum(ws[2 + h2:])
+        if len(fs) > NW + 2 and len(ws) > NW + 2 and len(fs) == len(ws):      # the two 400-step steady-state rollouts (each one or more launches): the second one
+            h2 = (len(fs) - NW - 1) // 2
+            f, w_ = sum(fs[NW + 1 + h2:]), sum(ws[NW + 1 + h2:])
             tot = 2 * f * 1024 + w_ * 1024
             lines.append(f"| {k} | second 400-step steady rollout ({h2} launch(es)) | {f:.1f} | {2 * f * 1024:.0f} | {w_:.1f} | {tot:.0f} | {tot / 400:.0f} B per step = {tot / 400 / 65536:.1f} B per env-step |")
             traffic[f"rollout_{layout}_{dt}_steady"] = {"bytes_per_step": tot / 400, "steps_in_measured_launch": 400}
