@@ -100,3 +100,60 @@ def test_shard_helpers():
     assert a.tolist() == [0, 1, 2, 0, 1, 2] and a.dtype == np.uint8
     r, l = ptg_dist.all_gather_finished([1.0, 2.0], [3, 4])        # no process group: identity
     assert r.tolist() == [1.0, 2.0] and l.tolist() == [3, 4]
+
+
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_total = 524288                                          # BASELINE config 5: 524 288 envs over 8 ranks
+        lo, hi = ptg_dist.shard_range(n_total, world, rank)
+        first_ptr, stride = ptg_dist.episode_plan(n_total, world, rank)
+        # every rank finishes all of its envs on the same step (a synchronised batch): 19 of them reported here, ragged by rank, so that
+        # ranks below and above the inline capacity (15) mix in one call
+        cnt = 10 + 2 * rank
+        r = (lo + np.arange(cnt)) * 0.25
+        l = np.full(cnt, 4603)
+        ra, la = ptg_dist.all_gather_finished(r, l)
+        flags = [ptg_dist.episode_boundary_in_window(12 if rank == 5 else 4000, 20), ptg_dist.episode_boundary_in_window(4000, 20)]
+        x = np.random.default_rng(7).normal(0.0, 2.0, (3, 64))[:, rank * 8:(rank + 1) * 8]
+        mom = np.stack([np.full(3, 8.0), x.mean(1), ((x - x.mean(1, keepdims=True)) ** 2).sum(1)], -1)
+        merged = ptg_dist.all_merge_moments(torch.from_numpy(mom)).numpy()
+        a = ptg_dist.mixed_scenario_assignment(n_total, world, rank, 3)
+        q.put((rank, (lo, hi), (first_ptr, stride), ra.tolist(), la.tolist(), flags, merged.tolist(), int(a[0]), int(a[-1]), len(a)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_gloo():
+    """The rank count of BASELINE config 5 (8 x MI355X), rehearsed on CPU: shards tile the batch, the episode plans tile the shared ep_index
+    order, one ragged all-gather with ranks on both sides of the inline capacity, the boundary decision and the moment merge agree on all ranks."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n_total = 524288
+    exp_r, exp_l = [], []
+    for rank in range(world):
+        cnt = 10 + 2 * rank
+        exp_r += ((rank * 65536 + np.arange(cnt)) * 0.25).tolist()
+        exp_l += [4603] * cnt
+    allx = np.random.default_rng(7).normal(0.0, 2.0, (3, 64))
+    for rank, rng, plan, ra, la, flags, merged, a0, a1, alen in out:
+        assert rng == (rank * 65536, (rank + 1) * 65536)                      # contiguous, equal shards
+        assert plan == (n_total + rank * 65536, n_total)                      # env e of the job takes eps_ind[N + e + m N]
+        assert ra == exp_r and la == exp_l                                    # rank order, every rank holds everything
+        assert flags == [True, False]
+        merged = np.array(merged)
+        assert merged[:, 0].tolist() == [64.0] * 3
+        np.testing.assert_allclose(merged[:, 1], allx.mean(1), rtol=1e-13)
+        np.testing.assert_allclose(merged[:, 2] / 64.0, allx.var(1), rtol=1e-12)
+        assert alen == 65536 and a0 == (rank * 65536) % 3 and a1 == ((rank + 1) * 65536 - 1) % 3      # scenario of GLOBAL env e = e mod 3
+    assert all(o[6] == out[0][6] for o in out)                                # bit-identical merge on every rank
