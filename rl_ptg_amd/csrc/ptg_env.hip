@@ -920,18 +920,37 @@ __device__ __forceinline__ const double* series(const HotParams& P, const double
 
 enum { NOISE_NONE = 0, NOISE_TAPE = 1, NOISE_RNG = 2 };
 
+// Select helpers of the state machine.  Both arms are VALUES computed before the call, so the front end emits an IR `select` and the
+// backend a v_cndmask: written as nested `?:` with arithmetic in the arms (or as a chain of `== constant` tests, which becomes a switch)
+// the same code compiled into exec-mask regions -- 87 s_and_saveexec / s_or / s_xor per producer step out of 450 instructions, and with one
+// producer wave per SIMD every instruction, scalar or not, is one 4-cycle issue slot of the loop-carried chain (round 3).
+__device__ __forceinline__ int sel(bool c, int a, int b) { return c ? a : b; }
+__device__ __forceinline__ int nib(unsigned table, int i) { return (int)((table >> (4 * i)) & 15u); }      // entry i of a table of 4-bit values
+// table ids of the six partial-load / full-load tables by their 3-bit state codes (part_tid / full_tid as register tables)
+__device__ __forceinline__ int part_tid_r(int p) { return nib(0xCBA985u, p); }                 // 5, 8, 9, 10, 11, 12
+__device__ __forceinline__ int full_tid_r(int q) { return 6 + nib(0xA98710u, q); }             // 6, 7, 13, 14, 15, 16
+
+// The ladder thresholds as registers: loaded from the workgroup's LDS image once (k_rollout_pc: once per launch, by the producers) with
+// six 16-byte reads instead of up to 21 conditional 4-byte reads inside every step that switches between partial and full load.
+struct Ladder { int v[LAD_N + 3]; };
+__device__ __forceinline__ void load_ladder(const HotLds& L, Ladder& G)
+{
+    const int4* q = (const int4*)L.lad;                      // (HotLds::lad sits at a 16-byte offset: int2 tm[18] = 144 bytes before it)
+#pragma unroll
+    for (int k = 0; k < (LAD_N + 3) / 4; k++) { const int4 x = q[k]; G.v[4 * k] = x.x; G.v[4 * k + 1] = x.y; G.v[4 * k + 2] = x.z; G.v[4 * k + 3] = x.w; }
+}
+
 // Integer state machine (:339-440, :525-757), branch-free.  Returns the record index.
 // ZPRE (tape mode, the rollout's producers): the env's next tape entry was fetched one step ahead and arrives in z_pre
 template <int NOISE, bool ZPRE = false>
-__device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
+__device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, const Ladder& G, const unsigned short* lut16, bool lds_lut,
                                         HotRegs& R, int act, int e, bool& changed, double z_pre = 0.0)
 {
     const unsigned f = R.flags;
     const int s = f & 7, sb = (f >> 4) & 1, su = (f >> 5) & 1, pp = (f >> 6) & 7, fq = (f >> 9) & 7;
     const unsigned mset = (f >> 15) & 3;
     const int tkey = (int)(f >> 17);
-    int hot = (f >> 3) & 1;
-    hot = (tkey <= P.key_cold_max) ? 0 : ((tkey >= P.key_hot_min) ? 1 : hot);        // :339-342
+    const int hot = sel(tkey <= P.key_cold_max, 0, sel(tkey >= P.key_hot_min, 1, (int)((f >> 3) & 1)));      // :339-342
     const int S = P.S, i0 = R.i, j0 = R.j;
     const int time_op = i0 + j0 * S;
     // :368-440 dispatch
@@ -940,9 +959,10 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
     const bool k3 = (act == 2) & (s <= 1);          // _startup
     const bool k4 = (act == 3) & (s == 4);          // _partial
     const bool k5 = (act == 4) & (s == 3);          // _full
-    const bool noisy = k1 | k2 | k3;
+    const bool noisy = k1 | k2 | k3, k45 = k4 | k5;
     const int sb_new = (tkey <= P.key_standby_max) ? 1 : 0;
-    const int dest = k1 ? (2 - sb_new) : k3 ? (3 + hot) : k4 ? 5 : 0;   // cooldown 0, standby_up 1, standby_down 2, startup_cold 3, startup_hot 4, op1 5
+    const int d_sb = 2 - sb_new, d_su = 3 + hot;
+    const int dest = sel(k1, d_sb, sel(k3, d_su, sel(k4, 5, 0)));       // cooldown 0, standby_up 1, standby_down 2, startup_cold 3, startup_hot 4, op1 5
     const unsigned li = (unsigned)(dest * P.nT + tkey);
     const int idx = lds_lut ? (int)lut16[li] : P.argidx[li];
     int i_noisy = 0;
@@ -958,24 +978,29 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
         x = (0 > x) ? 0 : x;
         i_noisy = (int)x;
     }
-    // _cont (:559-570): the table the env is in
-    const int t_cont = (s == 0) ? (PTG_T_STANDBY_DOWN + sb) : (s == 1) ? PTG_T_COOLDOWN : (s == 2) ? su : (s == 3) ? part_tid(pp) : full_tid(fq);
-    const int t_noisy = k1 ? (PTG_T_STANDBY_DOWN + sb_new) : k2 ? PTG_T_COOLDOWN : hot;     // startup_cold 0 / startup_hot 1
+    // _cont (:559-570): the table the env is in -- by state: standby, cooldown, startup, partial load, full load
+    const int t_sb = PTG_T_STANDBY_DOWN + sb, t_pp = part_tid_r(pp), t_fq = full_tid_r(fq);
+    const int t_cont = sel(s >= 4, t_fq, sel(s >= 3, t_pp, sel(s >= 2, su, sel(s >= 1, PTG_T_COOLDOWN, t_sb))));
+    const int t_sbn = PTG_T_STANDBY_DOWN + sb_new;
+    const int t_noisy = sel(k1, t_sbn, sel(k2, PTG_T_COOLDOWN, hot));     // startup_cold 0 / startup_hot 1
     int pp_l = 5, fq_l = 1, i_l = 0, j_l = 1;        // ladder results (_partial :627-691, _full :693-757)
-    if (__ballot(k4 | k5)) {
-        const int* lad = L.lad;
-        const int t = time_op;
-        {   // _partial, by full_op
+    if (__ballot(k45)) {
+        const int* lad = G.v;
+        const int t = time_op, j0p = j0 + 1, i_full = lad[LAD_I_FULL], j_full = lad[LAD_J_FULL];
+        int i_p, j_p, i_f, j_f;
+        {   // _partial, by full_op: the reference's if / elif chain, first match wins (applied last below)
             const bool a0 = t < lad[LAD_T2_START_F_P];
             const int T1 = lad[LAD_T1_P_F_P], T2 = lad[LAD_T2_P_F_P], TPF = lad[LAD_T_P_F], T34 = lad[LAD_T34_P_F_P],
                       T45 = lad[LAD_T45_P_F_P], T5 = lad[LAD_T5_P_F_P];
             const bool r1 = t < T1, r2 = (T1 < t) & (t < T2), r3 = (T2 < t) & (t < TPF), r4 = (TPF < t) & (t < T34),
                        r5 = (T34 < t) & (t < T45), r6 = (T45 < t) & (t < T5);
-            const int pp1 = r1 ? 5 : r2 ? 1 : r3 ? 1 : r4 ? 2 : r5 ? 3 : r6 ? 4 : 5;
-            const int i1 = r1 ? lad[LAD_I_FULL] : r2 ? i0 : r3 ? T2 : r4 ? lad[LAD_T3_P_F_P] : r5 ? lad[LAD_T4_P_F_P] : r6 ? T5 : 0;
-            const int j1 = r1 ? lad[LAD_J_FULL] : r2 ? j0 + 1 : 1;
-            pp_l = (fq == 0) ? (a0 ? 0 : 5) : (fq == 1) ? pp1 : 5;
-            if (k4) { i_l = (fq == 0) ? (a0 ? idx : 0) : (fq == 1) ? i1 : 0; j_l = (fq == 1) ? j1 : 1; }
+            const int pp1 = sel(r1, 5, sel(r2 | r3, 1, sel(r4, 2, sel(r5, 3, sel(r6, 4, 5)))));
+            const int i1 = sel(r1, i_full, sel(r2, i0, sel(r3, T2, sel(r4, lad[LAD_T3_P_F_P], sel(r5, lad[LAD_T4_P_F_P], sel(r6, T5, 0))))));
+            const int j1 = sel(r1, j_full, sel(r2, j0p, 1));
+            const bool f0 = fq == 0, f1 = fq == 1;
+            pp_l = sel(f0, sel(a0, 0, 5), sel(f1, pp1, 5));
+            i_p = sel(f0, sel(a0, idx, 0), sel(f1, i1, 0));
+            j_p = sel(f1, j1, 1);
         }
         {   // _full, by part_op
             const bool b0 = t < lad[LAD_T1_START_P_F];
@@ -983,20 +1008,26 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
                       T45 = lad[LAD_T45_F_P_F], T5 = lad[LAD_T5_F_P_F];
             const bool q1 = t < T1, q2 = (T1 < t) & (t < TFP), q3 = (TFP < t) & (t < T23), q4 = (T23 < t) & (t < T34),
                        q5 = (T34 < t) & (t < T45), q6 = (T45 < t) & (t < T5);
-            const int fq1 = q1 ? 1 : q2 ? 2 : q3 ? 2 : q4 ? 3 : q5 ? 4 : q6 ? 5 : 1;
-            const int i1 = q1 ? lad[LAD_I_FULL] : q2 ? i0 : q3 ? lad[LAD_T2_F_P_F] : q4 ? lad[LAD_T3_F_P_F] : q5 ? lad[LAD_T4_F_P_F] : q6 ? T5 : 0;
-            const int j1 = q1 ? lad[LAD_J_FULL] : q2 ? j0 + 1 : 1;
-            fq_l = (pp == 0) ? (b0 ? 0 : 1) : (pp == 5) ? fq1 : 1;
-            if (k5) { i_l = (pp == 5) ? i1 : 0; j_l = (pp == 5) ? j1 : 1; }
+            const int fq1 = sel(q1, 1, sel(q2 | q3, 2, sel(q4, 3, sel(q5, 4, sel(q6, 5, 1)))));
+            const int i1 = sel(q1, i_full, sel(q2, i0, sel(q3, lad[LAD_T2_F_P_F], sel(q4, lad[LAD_T3_F_P_F], sel(q5, lad[LAD_T4_F_P_F], sel(q6, T5, 0))))));
+            const int j1 = sel(q1, j_full, sel(q2, j0p, 1));
+            const bool p0 = pp == 0, p5 = pp == 5;
+            fq_l = sel(p0, sel(b0, 0, 1), sel(p5, fq1, 1));
+            i_f = sel(p5, i1, 0);
+            j_f = sel(p5, j1, 1);
         }
+        i_l = sel(k4, i_p, sel(k5, i_f, 0));
+        j_l = sel(k4, j_p, sel(k5, j_f, 1));
     }
-    const int pp_n = k3 ? 0 : k4 ? pp_l : pp;
-    const int fq_n = k3 ? 0 : k5 ? fq_l : fq;
-    int s_n = k1 ? 0 : k2 ? 1 : k3 ? 2 : k4 ? 3 : k5 ? 4 : s;
-    int i_n = noisy ? i_noisy : (k4 | k5) ? i_l : i0;
-    int j_n = noisy ? 1 : (k4 | k5) ? j_l : j0 + 1;
-    const int table = noisy ? t_noisy : k4 ? part_tid(pp_l) : k5 ? full_tid(fq_l) : t_cont;
-    const int sb_n = k1 ? sb_new : sb, su_n = k3 ? hot : su;
+    const int pp_n = sel(k3, 0, sel(k4, pp_l, pp));
+    const int fq_n = sel(k3, 0, sel(k5, fq_l, fq));
+    const int s_ev = sel(k1, 0, sel(k2, 1, sel(k3, 2, sel(k4, 3, sel(k5, 4, s)))));
+    const int j0n = j0 + 1;
+    int i_n = sel(noisy, i_noisy, sel(k45, i_l, i0));
+    int j_n = sel(noisy, 1, sel(k45, j_l, j0n));
+    const int t_pl = part_tid_r(pp_l), t_fl = full_tid_r(fq_l);
+    const int table = sel(noisy, t_noisy, sel(k4, t_pl, sel(k5, t_fl, t_cont)));
+    const int sb_n = sel(k1, sb_new, sb), su_n = sel(k3, hot, su);
     // _perform_sim_step (:525-557) against the virtual table [rows | splice-or-last-row padding]
     const int2 tm = L.tm[table];
     const int n = tm.x;
@@ -1005,11 +1036,12 @@ __device__ __forceinline__ int hot_ints(const HotParams& P, const HotLds& L, con
     const bool inside = over < 0;                    // start + S < n
     const bool is_su = table <= PTG_T_STARTUP_HOT;   // change_operation: startup -> partial load
     const bool head = over < S;
-    const int r = inside ? start : (is_su ? (head ? start : n) : min(start, n));
-    const bool splice = (!inside) & is_su;
-    s_n = splice ? 3 : s_n;
-    i_n = (splice & head) ? over : i_n;
-    j_n = (splice & head) ? 0 : j_n;
+    const int r_min = min(start, n), r_su = sel(head, start, n);
+    const int r = sel(inside, start, sel(is_su, r_su, r_min));
+    const bool splice = (!inside) & is_su, sh = splice & head;
+    const int s_n = sel(splice, 3, s_ev);
+    i_n = sel(sh, over, i_n);
+    j_n = sel(sh, 0, j_n);
     changed = (s != s_n);
     R.i = i_n; R.j = j_n;
     R.flags = (unsigned)s_n | (hot << 3) | (sb_n << 4) | (su_n << 5) | (pp_n << 6) | (fq_n << 9) | ((unsigned)act << 12) |
@@ -1042,7 +1074,7 @@ __device__ __forceinline__ void hot_load_market(const HotParams& P, HotLoads<OUT
 // k1 = step count after this step: UNIFORM (the hot kernels only run on a synchronised batch), so the clock arithmetic of
 // :442-445 is scalar; only the episode offset act_ep_d differs between envs
 template <bool MOD, int NOISE, typename OUT>
-__device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, const unsigned short* lut16, bool lds_lut,
+__device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, const Ladder& G, const unsigned short* lut16, bool lds_lut,
                                           HotRegs& R, int act, int e, int k1, HotLoads<OUT>& Q)
 {
     const unsigned mset = (R.flags >> 15) & 3;
@@ -1059,7 +1091,7 @@ __device__ __forceinline__ void hot_front(const HotParams& P, const HotLds& L, c
     Q.el = ld_off<double>(P.pool64, hb4 * 2u);
     Q.gas = ld_off<double>(P.pool64 + P.off_gas, db4 * 2u);
     Q.eua = ld_off<double>(P.pool64 + P.off_eua, db4 * 2u);
-    const int ridx = hot_ints<NOISE>(P, L, lut16, lds_lut, R, act, e, Q.changed);
+    const int ridx = hot_ints<NOISE>(P, L, G, lut16, lds_lut, R, act, e, Q.changed);
     typedef typename HotTypes<OUT>::rec_t rec_t;
     Q.rec = ld_off<rec_t>(rec_table(P, (const rec_t*)nullptr), (unsigned)ridx * 64u);
 }
@@ -1280,7 +1312,9 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, OUT* _
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const int act = hot_decode(actk, P, ri, rf, R.flags);
     HotLoads<OUT> Q;
-    hot_front<MOD, NOISE, OUT>(P, L, nullptr, false, R, act, e, k0 + 1, Q);
+    Ladder G;
+    load_ladder(L, G);
+    hot_front<MOD, NOISE, OUT>(P, L, G, nullptr, false, R, act, e, k0 + 1, Q);
     ST_STAMP(3);
     const OUT r = hot_back<OUT>(P, R, Q, setc, e, live);
 #ifdef PTG_STAMPS
@@ -1623,13 +1657,17 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
 #ifdef PTG_ABLATE_KEYLAG      // TIMING-ONLY ablation (wrong results): the state machine consumes the key gathered TWO steps ago (two registers used in
     unsigned tkB = 0;         // turn), so the newest gather is never on the loop-carried chain: the upper bound of what any key run-ahead / speculation
 #endif                        // scheme could gain for chain-bound shapes (small batches, SPLIT rows); tools/r03_keylag.sh
+    Ladder G;                                               // producers: the ladder thresholds, in registers for the whole launch
+    int code_nx = 0;                                        // producers: the NEXT step's action byte, read one step ahead of its use --
+    if (producer) { load_ladder(L, G); code_nx = s_act[lx]; }      // its address depends on nothing, its LDS latency need not sit on the chain
     auto produce_ = [&](const int it, unsigned& tk) {       // state machine of step `it`
         if (it > 0) R.flags = (R.flags & 0x1FFFFu) | (tk << 17);                  // Meth_T_cat = op[-1, 1] (:452)
-        const int code = s_act[it * NP + lx];
+        const int code = code_nx;
+        code_nx = s_act[min(it + 1, T - 1) * NP + lx];
         const int act = (code == 7) ? (int)((R.flags >> 12) & 7) : code;
         bool changed;
         const int nctr0 = R.nctr;
-        const int ridx = hot_ints<NOISE, NOISE == NOISE_TAPE>(P, L, lut, LDSLUT, R, act, e, changed, z_next);
+        const int ridx = hot_ints<NOISE, NOISE == NOISE_TAPE>(P, L, G, lut, LDSLUT, R, act, e, changed, z_next);
         tk = ld_off<unsigned short>(rkey, (unsigned)ridx * 2u);
         // tape mode: the draw the env will consume next is fetched as soon as the previous one is used up -- steps ahead of its use,
         // as a rule (a load inside the step that needs it is a second dependent round trip: 2.25 us per step against 1.5)
