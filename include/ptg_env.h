@@ -151,7 +151,7 @@ int ptg_set_episode_plan(ptg_env* env, const double* eps_ind_host, int n, int64_
 int ptg_set_noise_tape(ptg_env* env, const double* tape_host, int per_env_len);
 /* ... or the device's counter-based generator: the c-th draw of the env with GLOBAL index g is
  *   noise(seed, g, c) = cfg.noise * BoxMuller(u1, u2),  (u1, u2) from three rounds of the 32-bit integer finaliser "lowbias32"
- *   keyed by (seed, g, c); Box-Muller in float32 with the native log / cos.
+ *   keyed by (seed, g, c); Box-Muller in float32 with the hardware log2 / sqrt / cos instructions.
  * ptg_set_noise_rng draws it inside the step kernels (no tape, unbounded); ptg_fill_noise_tape writes the first per_env_len
  * draws of the same streams to the tape (so both modes give identical trajectories while the tape does not wrap).
  * Both reset the per-env draw counters.  Statistically equivalent to, not bit-equal with, NumPy's Generator.normal. */

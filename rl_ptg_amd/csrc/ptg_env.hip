@@ -199,7 +199,7 @@ k_build_argmin(const double* __restrict__ tab, int n, const double* __restrict__
 // ------------------------------------------------------------------------------------------------ noise tape RNG
 // c-th normal(0, sigma) draw of global env eg: a counter-based generator built from three rounds of the 32-bit
 // integer finaliser "lowbias32" (x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16) keyed by
-// (seed, eg, c), then Box-Muller in float32 with the native log / cos (~30 VALU instead of ~150 for Philox4x32-10 +
+// (seed, eg, c), then Box-Muller in float32 with the hardware's log2 / sqrt / cos instructions (~30 VALU instead of ~150 for Philox4x32-10 +
 // float64 Box-Muller; the draw only jitters a table row index by ~10 rows).  The same function fills tapes
 // (k_fill_noise) and draws in-kernel, so both modes agree bit for bit.
 __device__ __forceinline__ unsigned lowbias32(unsigned x)
@@ -214,8 +214,11 @@ __device__ __forceinline__ double noise_draw(unsigned long long seed, long long 
     const unsigned k2 = lowbias32(k1 ^ 0xC2B2AE35u);
     const float u1 = ((float)(k1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u2 = ((float)(k2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * __logf(u1));
-    return sigma * (double)(r * __cosf(6.28318530717958647692f * u2));
+    // the hardware's own log2 / sqrt / cos-of-revolutions (v_log_f32, v_sqrt_f32, v_cos_f32: one instruction each; u1 is never a denormal
+    // and u2 lies in (0, 1), so the library versions' range handling -- ~45 of the 75 instructions of a draw -- bought nothing):
+    // -2 ln u1 = -2 ln 2 * log2 u1
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    return sigma * (double)(r * __builtin_amdgcn_cosf(u2));
 }
 
 // The device tape is draw-major, [L][N]: lane e of a wave reads draw (noise_count[e] % L) of env e, and envs that consumed the same
