@@ -30,8 +30,18 @@ def short(name):
     return name[:60]
 
 
+def newest(pattern):
+    """files of the most recent profiler run only (gpurun merges its output directory: an older run's <pid>_*.csv may still lie beside the new one)"""
+    fs = glob.glob(pattern, recursive=True)
+    if not fs:
+        return []
+    last = max(fs, key=os.path.getmtime)
+    pid = os.path.basename(last).split("_")[0]
+    return [f for f in fs if os.path.basename(f).split("_")[0] == pid and os.path.dirname(f) == os.path.dirname(last)]
+
+
 rows = []
-for f in glob.glob(f"gpurun_out/prof_{tag}_trace/**/*kernel_stats.csv", recursive=True):
+for f in newest(f"gpurun_out/prof_{tag}_trace/**/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         rows.append(r)
 with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as out:
@@ -43,7 +53,7 @@ with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as out:
 
 trace = defaultdict(list)
 meta = {}
-for f in glob.glob(f"gpurun_out/prof_{tag}_trace/**/*kernel_trace.csv", recursive=True):
+for f in newest(f"gpurun_out/prof_{tag}_trace/**/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         trace[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
@@ -51,7 +61,7 @@ for f in glob.glob(f"gpurun_out/prof_{tag}_trace/**/*kernel_trace.csv", recursiv
 
 pmc = defaultdict(lambda: defaultdict(list))          # kernel -> counter -> [(dispatch id, value)]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(f"gpurun_out/prof_{tag}_{c}/**/*counter_collection.csv", recursive=True):
+    for f in newest(f"gpurun_out/prof_{tag}_{c}/**/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 
