@@ -471,11 +471,10 @@ def main():
         return out
 
     def wake():
-        """Device pre-conditioning before the first leg, outside every timed region: a scratch handle runs two 200-step rollouts and is
-        closed again.  The first leg of a fresh process otherwise now and then reads 5 us more for the same 20-step launch than the later
-        legs do (38.9 against 33.1-33.3 us on one box, profiles/r03_bench_driver_args.json's sibling run): the first kernels of a process
-        after the table build find the memory system in another state than every later leg does.  The timed leg itself is unchanged
-        (fresh handle -> reset -> W warm-up steps -> K timed steps)."""
+        """EXPERIMENT (PTG_BENCH_WAKE=1; off by default): device pre-conditioning before the first leg -- a scratch handle runs two
+        200-step rollouts and is closed again.  Measured: it does not help, it hurts (33.1-37.2 us for the timed launch against 33.2-33.6
+        without it): the leg that allocates its buffers FIRST in the process is the fast one (profiles/r03_bench_spread.txt), which is
+        also why the headline leg stays the first leg (PTG_BENCH_ORDER=head_last: 34.4-37.4 us)."""
         eng = HipEngine(spec.consts, spec.tables, spec.markets, min(n, 65536), device=local_rank, out_dtype="float32", obs_layout="row")
         eng.set_episode_plan(spec.eps_ind, first_ptr, stride)
         eng.set_noise_rng(seed=1)
