@@ -1174,12 +1174,21 @@ struct RowTile {
     // (float64 rows: pitch 35 doubles = 70 dwords -- lanes l, l + 1 start 6 banks apart, an 8-byte store per lane is conflict-free)
     static constexpr int PITCH = (F == 40) ? 41 : (F == 16) ? 17 : F;
     static constexpr int TILE = 64 * PITCH;                // elements per wave
+    typedef __attribute__((address_space(3))) OUT lds_out;
     OUT* t;                                                // this wave's [64][PITCH] tile
     int lane;
-    __device__ __forceinline__ RowTile(OUT* tiles, int wave) : t(tiles + wave * TILE), lane(threadIdx.x & 63) {}
+    lds_out* r;                                            // this lane's row of the tile, as an LDS byte address held in ONE register:
+    // left to the compiler the address is (constant offset of the tiles in LDS) + (lane part), and the constant does not fit the 8-bit
+    // offsets of the paired ds_write2_b32 a row is written with -- it then spends one v_add per pair and step (18 of a consumer's ~245
+    // instructions) re-adding it.  Laundered through an empty asm the sum is opaque and the columns become immediate offsets.
+    __device__ __forceinline__ RowTile(OUT* tiles, int wave) : t(tiles + wave * TILE), lane(threadIdx.x & 63)
+    {
+        unsigned a = (unsigned)(size_t)(lds_out*)(t + lane * PITCH);
+        asm volatile("" : "+v"(a));
+        r = (lds_out*)(size_t)a;
+    }
     __device__ __forceinline__ void put(int q, OUT v) const
     {
-        OUT* r = t + lane * PITCH;
         if (SPLIT) {
             if (q < QS) return;
             if (q == QS) {
@@ -1196,7 +1205,7 @@ struct RowTile {
     __device__ __forceinline__ void put_u(int q, OUT v) const { put(q, v); }
     __device__ __forceinline__ void put_idx(unsigned hour_idx, unsigned day_idx) const
     {
-        if (SPLIT) { OUT* r = t + lane * PITCH; r[14] = (OUT)hour_idx; r[15] = (OUT)day_idx; }
+        if (SPLIT) { r[14] = (OUT)hour_idx; r[15] = (OUT)day_idx; }
     }
     // rows = address of the wave's first row; all 64 lanes of the wave must be live
     // PARTIAL = false: all 64 rows exist.  PARTIAL = true: only the first n_valid rows do (the batch's last, ragged wave): whole
