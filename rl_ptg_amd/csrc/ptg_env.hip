@@ -1240,6 +1240,28 @@ struct RowTile {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // flush of a full tile with THREE 16-byte pieces in flight.  The plain loop above compiles to read - wait - store nine times over (the
+    // compiler reuses one register quartet): nine LDS round trips per step, exposed where no second wave fills the SIMD -- small batches:
+    // 0.65 -> 0.60 us per fused step at 4 096 envs.  At 65 536 envs (two waves per SIMD) it bought nothing and the first launch after a
+    // reset measured ~1 us slower (profiles/r03_prologue_ab.txt), so k_rollout_pc takes it for small workgroups only.
+    __device__ __forceinline__ void flush3(OUT* rows) const
+    {
+        if constexpr (PITCH != F) { flush(rows); return; }
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int NJ = (N4 + 63) / 64;
+#pragma unroll
+            for (int j0 = 0; j0 < NJ; j0 += 3) {
+                vf4 v[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int g = lane + 64 * (j0 + u); if (j0 + u < NJ && g < N4) v[u] = ((const vf4*)t)[g]; }
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int g = lane + 64 * (j0 + u); if (j0 + u < NJ && g < N4) __builtin_nontemporal_store(v[u], (vf4*)rows + g); }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 };
 
 template <bool MOD, class Sink, typename OUT>
@@ -1744,7 +1766,7 @@ k_rollout_pc(const HotParams P, const void* __restrict__ actions, int actk, int 
             const int cw = (int)(threadIdx.x >> 6) - (NP >> 6);
             const RowTile<MOD, FLAT, OUT, SPLIT> tile(s_tiles, cw);
             emit(tile);
-            if (wave_full) tile.flush(rows);
+            if (wave_full) { if (NP < 256) tile.flush3(rows); else tile.flush(rows); }      // (uniform: the workgroup size of the launch)
             else tile.template flush<true>(rows, P.N - e_wave);
         }
         // lanes past the batch shadow env N - 1 and store what its real lane stores, to the same addresses: no divergent region
