@@ -182,3 +182,63 @@ def test_full_size_slice_vs_oracle(n, scenario, operation, noise, out_dtype):
     assert len(np.unique(ints[:, 0])) >= 4                   # the slice went through (nearly) every METH_STATUS
     assert int(eng.get_state("noise_count")[lo:lo + m].max()) <= L
     eng.close(); ora.close()
+
+
+@pytest.mark.parametrize("scenario,operation,out_dtype,layout", [(2, "OP2", "float32", "row"), (1, "OP1", "float64", "row"), (3, "OP2", "float32", "feature")])
+def test_real_training_set_every_env_its_own_episode_vs_oracle(scenario, operation, out_dtype, layout):
+    """The reference's REAL training set (tests/golden/market_real.npz: 36 552 hours) with its default episode length (37 days, 41 episodes)
+    through `rl_ptg_amd.prep.Preprocessing`: 1 024 envs in DummyVecEnv order, so every env sits in its own draw of the shuffled eps_ind
+    (`src/rl_utils.py:315-335`) and the market windows are per-lane gathers -- 120 single steps then 200 fused steps against the oracle."""
+    from rl_ptg_amd.config import EnvConfig
+    from rl_ptg_amd.engine import HipEngine
+    from rl_ptg_amd.prep import EnvSpec, Preprocessing
+    z = np.load(os.path.join(H.GOLD, "market_real.npz"))
+    prices = {k: z[k] for k in z.files}
+    cfg = EnvConfig(scenario=scenario, operation=operation)
+    pre = Preprocessing(prices, H.load_tables(operation), cfg, seed_train=3654, train_steps=1500000, action_type="discrete")
+    spec = EnvSpec.from_dict_input(pre.dict_env_kwargs("train"), "train")
+    assert pre.n_eps == 41 and len(spec.eps_ind) == 2460 and spec.consts["eps_sim_steps"] == 5328      # SURVEY.md 8(c) known answers
+    n, K1, K2 = 1024, 120, 200          # (constructors + first resets draw 2 n of the 2 460 eps_ind entries: the reference raises IndexError beyond)
+    eng = HipEngine(spec.consts, spec.tables, spec.markets, n, device=0, out_dtype=out_dtype, obs_layout=layout)
+    eng.set_episode_plan(spec.eps_ind, n, n)
+    rng = np.random.default_rng(31 + scenario)
+    tape = rng.normal(0.0, spec.consts["noise"], size=(n, 64))
+    eng.set_noise_tape(tape)
+    m = spec.markets[0]
+    consts = dict(spec.consts, scenario=m["scenario"], rew_l_b=m["rew_l_b"], rew_u_b=m["rew_u_b"], r_0=m["r_0"])
+    ora = H.po.OracleVecEnv(consts, spec.tables, dict(m, eps_ind=spec.eps_ind), n, ep_index0=0)
+    ora.set_noise_tape(tape)
+    rtol, atol = (RTOL64, ATOL64) if out_dtype == "float64" else (RTOL32, ATOL32)
+    ratol = max(atol, 1e-6 if out_dtype == "float32" else 0)
+    o_ref, _ = ora.reset()
+    np.testing.assert_allclose(eng.rows(eng.reset()).cpu().numpy(), o_ref, rtol=rtol, atol=atol)
+    assert len(np.unique(eng.get_state("act_ep_d"))) > 30          # the envs really are spread over the episodes
+    hold = rng.integers(1, 10, n)
+    cur = np.full(n, 2)
+
+    def acts_at(t):
+        nonlocal cur
+        flip = t % hold == 0
+        cur = np.where(flip & (t > 8), rng.integers(0, 5, n), cur)
+        return cur.astype(np.int32)
+
+    for t in range(K1):
+        a = acts_at(t)
+        o, r, d = eng.step(a)
+        eng.sync()
+        o_ref, r_ref, d_ref, _, _ = ora.step(a)
+        np.testing.assert_allclose(eng.rows(o).cpu().numpy(), o_ref, rtol=rtol, atol=atol, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=rtol, atol=ratol, err_msg=f"reward step {t}")
+    acts = np.stack([acts_at(K1 + t) for t in range(K2)])
+    obs, rew, done = eng.rollout(acts)
+    eng.sync()
+    obs, rew = obs.cpu(), rew.cpu().numpy()
+    for t in range(K2):
+        o_ref, r_ref, d_ref, _, _ = ora.step(acts[t])
+        np.testing.assert_allclose(eng.rows(obs[t]).numpy(), o_ref, rtol=rtol, atol=atol, err_msg=f"obs fused step {t}")
+        np.testing.assert_allclose(rew[t], r_ref, rtol=rtol, atol=ratol, err_msg=f"reward fused step {t}")
+    ints, f64s = ora.state()
+    got = _ints(eng)
+    assert np.array_equal(got[:, :10], ints[:, :10]) and np.array_equal(got[:, 11], ints[:, 11])
+    assert np.array_equal(eng.get_state("T_cat"), f64s[:, 2])
+    eng.close(); ora.close()
