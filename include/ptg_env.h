@@ -231,11 +231,17 @@ int ptg_host_buffers_changed(ptg_env* env);
 /* hipGraph capture.  ptg_step / ptg_rollout enqueue kernels only (no synchronisation, no host round trip), so they can be captured on
  * `stream` -- e.g. together with the policy's forward pass, whose ~10 launches per step otherwise bound a device-resident collect loop
  * (profiles/r03_policy_loop.txt) -- and the captured launches can be REPLAYED: the hot kernels read the common step count from the device
- * state.  Two things the host does for eager calls cannot happen inside a replay, so the caller does them:
- *   * the one step per episode that terminates goes through another kernel: replay at most ptg_steps_to_episode_end() - 1 steps, then make
- *     that step an eager call (a hot kernel that finds itself on the terminating step raises PTG_E_INVALID at the next synchronising call);
- *   * ptg_note_replays(env, n): after replaying captured launches that together advanced the batch by n vector steps (the capture itself
- *     counts as executed steps already), so that eager calls, ptg_steps_to_episode_end and ptg_rollout_launches stay in step.
+ * state.
+ *   * A captured ptg_step is replay-proof: while `stream` is being captured the step is enqueued as the hot kernel, which does nothing when
+ *     it finds the batch on the terminating step of the episode, plus the generic kernel behind it, which does nothing otherwise -- a
+ *     replay takes the right one by itself, across episode ends, auto-reset (episode plan) and finished-episode list included, for the
+ *     price of one empty launch per step.  final_obs_dev of the captured call receives the terminal observations.
+ *   * A captured ptg_rollout must not be replayed across an episode end (a fused launch cannot terminate; eager calls are cut there by
+ *     the host): ptg_steps_to_episode_end() says how far it may go; a replay that runs over raises PTG_E_INVALID at the next
+ *     synchronising call.
+ *   * ptg_note_replays(env, n): after replaying captured launches that together advanced the batch by n vector steps BEYOND the first
+ *     replay (the capture call counts as executed once, like an eager call), so that eager calls, ptg_steps_to_episode_end,
+ *     ptg_rollout_launches and ptg_finished_episodes stay in step; the count wraps at the episode length.
  * Buffers are the graph's (fixed addresses); kernel-flagged errors surface at the next ptg_sync / ptg_step_host / ptg_finished_episodes.
  * No reference counterpart. */
 int ptg_note_replays(ptg_env* env, int n_steps);

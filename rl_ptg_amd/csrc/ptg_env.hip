@@ -111,6 +111,8 @@ struct DevParams {
     int split;                            // SPLIT layout (16 columns: status one-hot, 8 env features, hour / day series index; q_stat set too)
     int* err;                             // [2] in pinned HOST memory: {invalid action seen, price index out of range}; kernels store 1 (plain
                                           // stores of a constant need no atomic), the host reads it after a stream synchronise -- no copy
+    int* term_flag;                       // device word: "the hot step kernel of this (captured) step found the batch on the terminating step
+                                          // and skipped it" -- written by k_step_hot, read by the k_step enqueued behind it
 };
 
 __device__ __forceinline__ int part_tid(int p) { return p == 0 ? PTG_T_OP1_START_P : 7 + p; }          // 5, 8..12
@@ -671,8 +673,12 @@ __device__ __forceinline__ void push_finished(const DevParams& P, bool done, int
 template <typename OUT, bool FAST, bool INFO, bool FM, int PAC>
 __global__ void __launch_bounds__(256)
 k_step(const DevParams P, const void* __restrict__ actions, int action_kind, OUT* __restrict__ obs, OUT* __restrict__ rew,
-       uint8_t* __restrict__ done, OUT* __restrict__ final_obs, double* __restrict__ info)
+       uint8_t* __restrict__ done, OUT* __restrict__ final_obs, double* __restrict__ info, int only_at_k)
 {
+    // only_at_k >= 0: the second kernel of a CAPTURED hot step (ptg_step while `stream` is being captured): the launch acts only when the
+    // hot kernel in front of it found the synchronised batch on the episode's terminating step and skipped it; it is a no-op otherwise
+    // (the hot kernel's flag, not the step count: after an ordinary step the count may have just ARRIVED at only_at_k)
+    if (only_at_k >= 0 && *P.term_flag == 0) return;
     __shared__ int2 s_tm[NT];
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e < P.N;
@@ -850,6 +856,7 @@ struct HotParams {
     const int* ladder;                                // [LAD_N]
     StA* st_a; StB* st_b; StC* st_c;
     int* err;
+    int* term_flag;
 };
 
 struct HotLds {                  // per-workgroup LDS image
@@ -1321,7 +1328,7 @@ __device__ unsigned long long g_stamps[256][2][8];
 template <int LAY, bool MOD, int NOISE, typename OUT>
 __global__ void __launch_bounds__(256)
 k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, OUT* __restrict__ obs, OUT* __restrict__ rew,
-           uint8_t* __restrict__ done)
+           uint8_t* __restrict__ done, int skip_term)
 {
     constexpr bool FM = LAY == PTG_OBS_FEATURE_MAJOR, FLAT = LAY == PTG_OBS_SB3_FLAT, SPLIT = LAY == PTG_OBS_SPLIT;
     __shared__ HotLds L;
@@ -1342,7 +1349,11 @@ k_step_hot(const HotParams P, const void* __restrict__ actions, int actk, OUT* _
     // step, say) can be replayed step after step.  What a replay cannot do is route the one terminating step of an episode to the generic
     // kernel -- the host does that for eager calls --, so a hot kernel that finds itself on that step raises the sequence flag (ptg_note_replays).
     const int k0 = __builtin_amdgcn_readfirstlane(a.k);
-    if (k0 >= P.eps_sim_steps - 6) { if (threadIdx.x == 0) P.err[2] = 1; }
+    if (skip_term) {                                        // captured form: tell the generic kernel enqueued behind this one whether the step is its
+        const bool term = k0 >= P.eps_sim_steps - 6;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *P.term_flag = term ? 1 : 0;
+        if (term) return;
+    } else if (k0 >= P.eps_sim_steps - 6) { if (threadIdx.x == 0) P.err[2] = 1; }
     const double2 setc = P.setc[(R.flags >> 15) & 3];
     const int act = hot_decode(actk, P, ri, rf, R.flags);
     HotLoads<OUT> Q;
@@ -2042,6 +2053,7 @@ struct ptg_env {
     std::vector<double> pool64_host;
     int* d_ladder = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
+    int step_skip_term = 0;      // argument of the next k_step_hot launch: 1 while ptg_step is being captured (see ptg_step)
     // VecNormalize reward normalisation (ptg_vn_*): per-env discounted returns, running (mean, var, count), scratch
     double *vn_returns = nullptr, *vn_stats = nullptr, *vn_partials = nullptr, *vn_den = nullptr, *vn_moments = nullptr;
     size_t vn_partials_cap = 0; int vn_T_cap = 0;
@@ -2360,6 +2372,7 @@ HotParams make_hot_params(const ptg_env* h)
     c.h2r_lo = P.h2r_lo; c.h2r_rng = P.h2r_rng; c.h2o_lo = P.h2o_lo; c.h2o_rng = P.h2o_rng; c.heat_lo = P.heat_lo; c.heat_rng = P.heat_rng;
     F.recf = P.recf; F.tape = P.tape; F.pool32 = h->d_pool32; F.pool64 = h->d_pool64; F.setc = P.setc; F.argidx = P.argidx;
     F.tabmeta = P.tabmeta; F.ladder = h->d_ladder; F.st_a = P.st_a; F.st_b = P.st_b; F.st_c = P.st_c; F.err = P.err;
+    F.term_flag = P.term_flag;
     return F;
 }
 
@@ -2389,9 +2402,9 @@ void launch_step_hot(ptg_env* h, hipStream_t st, const void* actions, int kind, 
     if (h->profiling) {
         hipEvent_t e0, e1;
         prof_pair(h, e0, e1);
-        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, obs, rew, done);
+        hipExtLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, e0, e1, 0, hp, actions, kind, obs, rew, done, h->step_skip_term);
     } else
-        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, hp, actions, kind, obs, rew, done);
+        hipLaunchKernelGGL((k_step_hot<LAY, MOD, NOISE, OUT>), grid, block, 0, st, hp, actions, kind, obs, rew, done, h->step_skip_term);
 }
 
 }  // namespace ptg_hot
@@ -2652,8 +2665,8 @@ int check_error_flags(ptg_env* h)          // after the stream has been synchron
     }
     if (__atomic_load_n(&e[2], __ATOMIC_RELAXED)) {
         __atomic_exchange_n(&e[2], 0, __ATOMIC_RELAXED);
-        return set_err(h, PTG_E_INVALID, "a hot step / rollout kernel ran on the terminating step of an episode: a captured launch was replayed "
-                       "past ptg_steps_to_episode_end (that step needs an eager call), or replays were not reported with ptg_note_replays");
+        return set_err(h, PTG_E_INVALID, "a hot kernel ran on the terminating step of an episode: a captured ptg_rollout was replayed past "
+                       "ptg_steps_to_episode_end (a fused launch cannot cross an episode end), or replays were not reported with ptg_note_replays");
     }
     return 0;
 }
@@ -2880,6 +2893,8 @@ int ptg_create(const ptg_config* cfg, const ptg_tables* tables, const ptg_market
         h->err_host[0] = 0; h->err_host[1] = 0; h->err_host[2] = 0; h->err_host[3] = 0;
         P.err = (int*)dp;
     }
+    if ((rc = dev_alloc(h, &P.term_flag, 4))) return fail(rc);
+    if (hipMemset(P.term_flag, 0, 4 * sizeof(int)) != hipSuccess) { set_err(h, PTG_E_HIP, "hipMemset failed"); return fail(PTG_E_HIP); }
     {   // pinned staging of ptg_finished_episodes, sized for the whole ring (allocated here: a first query pays no hipHostMalloc)
         const size_t need = (size_t)P.fin_cap * (sizeof(double) + 2 * sizeof(int));
         if (hipHostMalloc(&h->fin_stage, need, hipHostMallocDefault) == hipSuccess) h->fin_stage_bytes = need;
@@ -3082,14 +3097,14 @@ int ptg_reset(ptg_env* h, const uint8_t* mask_host, void* obs_dev, void* stream)
 
 // generic (any configuration, handles termination + auto-reset) launch of one vector step
 static int launch_step_generic(ptg_env* h, hipStream_t st, const void* actions_dev, int action_kind, void* obs_dev, void* rew_dev,
-                               uint8_t* done_dev, void* final_obs_dev, double* info_dev)
+                               uint8_t* done_dev, void* final_obs_dev, double* info_dev, int only_at_k = -1)
 {
     const dim3 grid(grid_for(h->n, 256)), block(256);
     const bool f64 = h->cfg.out_dtype == PTG_OUT_F64;
     h->fin_maybe = true;
 #define PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, PAC)                                                                     \
     hipLaunchKernelGGL((k_step<OUT, FAST, INFO, FM, PAC>), grid, block, 0, st, h->P, actions_dev, action_kind, (OUT*)obs_dev, \
-                       (OUT*)rew_dev, done_dev, (OUT*)final_obs_dev, info_dev)
+                       (OUT*)rew_dev, done_dev, (OUT*)final_obs_dev, info_dev, only_at_k)
 #define PTG_LAUNCH_STEP(OUT, FAST, INFO, FM)                                                                          \
     do { if (h->cfg.price_ahead == 13) PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, 13); else PTG_LAUNCH_STEP_(OUT, FAST, INFO, FM, 0); } while (0)
     if (f64) {
@@ -3133,9 +3148,20 @@ int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev
     hipStream_t st = as_stream(stream);
     const int k_term = h->cfg.eps_sim_steps - 6;               // the step taken at k == k_term terminates (:508-511)
     if (hot_eligible(h) && !info_dev && h->sync_k != k_term) {
+        // Being captured into a hipGraph, the step is enqueued in its replay-proof form: the hot kernel, which does nothing when it finds
+        // the batch on the terminating step, and behind it the generic kernel, which does nothing unless the batch stands there.  Every
+        // replay then takes the right one by itself -- across episode ends, auto-reset and finished-episode list included -- for the
+        // price of one empty launch per step.  (Eager calls are routed on the host as before.)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        const bool capturing = cs != hipStreamCaptureStatusNone;
+        h->step_skip_term = capturing ? 1 : 0;
         PTG_HOT_DISPATCH(launch_step_hot, h, st, actions_dev, action_kind, PTG_NOARG, obs_dev, rew_dev, done_dev);
+        h->step_skip_term = 0;
+        int rc = launch_check(h, "k_step_hot");
+        if (!rc && capturing) rc = launch_step_generic(h, st, actions_dev, action_kind, obs_dev, rew_dev, done_dev, final_obs_dev, nullptr, k_term);
         h->sync_k += 1;
-        return launch_check(h, "k_step_hot");
+        return rc;
     }
     const int rc = launch_step_generic(h, st, actions_dev, action_kind, obs_dev, rew_dev, done_dev, final_obs_dev, info_dev);
     if (h->sync_k >= 0) h->sync_k = (h->sync_k == k_term) ? 0 : h->sync_k + 1;   // a synchronised batch resets together
@@ -3226,11 +3252,11 @@ int ptg_note_replays(ptg_env* h, int n_steps)
 {
     if (!h || n_steps < 0) return set_err(h, PTG_E_INVALID, "ptg_note_replays: bad argument");
     if (h->sync_k < 0) return set_err(h, PTG_E_INVALID, "ptg_note_replays: the batch is not synchronised (captured hot launches do not exist for it)");
-    const int k_term = h->cfg.eps_sim_steps - 6;
-    if (h->sync_k + n_steps > k_term)
-        return set_err(h, PTG_E_INVALID, "ptg_note_replays: %d replayed steps from step %d run over the terminating step %d of the episode",
-                       n_steps, h->sync_k, k_term);
-    h->sync_k += n_steps;
+    // a captured ptg_step carries its own terminating-step kernel: replays may run across episode ends (the step count wraps at k_term + 1).
+    // (A captured ptg_rollout must not: its kernel flags the overrun, see check_error_flags.)
+    const long long period = (long long)(h->cfg.eps_sim_steps - 6) + 1;
+    h->sync_k = (int)(((long long)h->sync_k + n_steps) % period);
+    h->fin_maybe = true;
     return 0;
 }
 

@@ -1,7 +1,7 @@
 """hipGraph replay of the hot path (include/ptg_env.h, "hipGraph capture"): `ptg_step` / `ptg_rollout` captured once and replayed step after
 step give what eager calls give, bit for bit -- the kernels take the step count from the device state -- and `ptg_note_replays` keeps the
-host's count (which routes an episode's terminating step, env/ptg_gym_env.py:508-511, to the generic kernel) in step.  A replay that runs
-over the terminating step is reported, not silently wrong."""
+host's count (which routes an episode's terminating step, env/ptg_gym_env.py:508-511, to the generic kernel) in step.  A captured step
+carries its own terminating-step kernel and replays across episode ends; a captured rollout that runs over one is reported, not silently wrong."""
 import numpy as np
 import pytest
 
@@ -88,23 +88,65 @@ def test_captured_rollout_replayed_equals_one_long_rollout():
     A.close(); B.close()
 
 
-def test_replay_over_the_terminating_step_is_reported():
+def test_captured_step_replays_across_episode_ends():
+    """A captured ptg_step is enqueued as the hot kernel + the generic kernel behind it (each a no-op when the step is the other's): replayed
+    over two and a half episodes it terminates, auto-resets over the episode plan and fills the finished-episode list exactly as eager
+    calls do."""
     import torch
-    n = 256
+    n = 300
     spec, A, B = _pair(n, sim_step=3600)                    # 4-day episodes of hourly steps: 96 steps, the 91st call terminates
+    to_end = spec.consts["eps_sim_steps"] - 5
+    R = 2 * to_end + 40
+    rng = np.random.default_rng(9)
+    acts = torch.as_tensor(rng.integers(0, 5, (R + 4, n)).astype(np.int32), device="cuda")
+    A.reset(); B.reset()
+    act_buf = torch.zeros(n, dtype=torch.int32, device="cuda")
+    obs, rew, done = B.alloc_obs(1)[0], torch.zeros(n, dtype=B.out_dtype, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    fin = torch.zeros_like(obs)
+    g = _capture(lambda: B.step(act_buf, obs, rew, done, final_obs=fin))
+    n_done = 0
+    for t in range(R):
+        act_buf.copy_(acts[t])
+        g.replay()
+        o_ref, r_ref, d_ref = A.step(acts[t])
+        torch.cuda.synchronize()
+        assert torch.equal(done, d_ref), f"done flags, replay {t}"
+        assert torch.equal(obs, o_ref) and torch.equal(rew, r_ref), f"replay {t}"
+        if bool(d_ref.any()):
+            n_done += 1
+            assert bool(d_ref.all()) and torch.equal(fin, A.final_obs)      # terminal observations of the step that ended the episodes
+    assert n_done == 2
+    B.note_replays(R - 1)
+    assert A.steps_to_episode_end() == B.steps_to_episode_end()
+    ra, la, ea = A.finished_episodes()
+    rb, lb, eb = B.finished_episodes()
+    assert len(ra) == 2 * n and np.array_equal(np.sort(ea), np.sort(eb))
+    oa, ob = np.lexsort((la, ea)), np.lexsort((lb, eb))
+    assert np.array_equal(ra[oa], rb[ob]) and np.array_equal(la[oa], lb[ob])
+    for t in range(R, R + 4):
+        xa = A.step(acts[t], want_final=False)
+        xb = B.step(acts[t], want_final=False)
+        torch.cuda.synchronize()
+        assert all(torch.equal(p, q) for p, q in zip(xa, xb))
+    for f in ("meth_state", "i", "j", "k", "noise_count", "act_ep_d", "cum_rew"):
+        assert np.array_equal(A.get_state(f), B.get_state(f)), f
+    A.close(); B.close()
+
+
+def test_captured_rollout_replayed_over_an_episode_end_is_reported():
+    """A fused launch cannot cross an episode end (the host cuts eager rollouts there): a replay that does is flagged, not silently wrong."""
+    import torch
+    n, T = 256, 30
+    spec, A, B = _pair(n, sim_step=3600)
     A.close()
     B.reset()
-    to_end = B.steps_to_episode_end()
-    assert to_end == spec.consts["eps_sim_steps"] - 5
-    act_buf = torch.full((n,), 2, dtype=torch.int32, device="cuda")
-    obs, rew, done = B.alloc_obs(1)[0], torch.zeros(n, dtype=B.out_dtype, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
-    g = _capture(lambda: B.step(act_buf, obs, rew, done, want_final=False))
-    with pytest.raises(RuntimeError, match="run over the terminating step"):
-        B.note_replays(to_end)                              # more than the hot kernels may run
-    for _ in range(to_end - 1):                             # all the steps a hot kernel may take ...
+    act_buf = torch.full((T, n), 2, dtype=torch.int32, device="cuda")
+    obs, rew, done = B.alloc_obs(T), torch.zeros((T, n), dtype=B.out_dtype, device="cuda"), torch.zeros((T, n), dtype=torch.uint8, device="cuda")
+    g = _capture(lambda: B.rollout(act_buf, obs, rew, done))
+    for _ in range(3):                                      # steps 0 .. 89: the hot kernels' share of the 96-step episode
         g.replay()
-    B.sync()                                                # ... are fine
-    g.replay()                                              # the terminating step through a hot kernel
+    B.sync()
+    g.replay()                                              # steps 90 .. 119 would run over the terminating step (call 91)
     with pytest.raises(RuntimeError, match="terminating step"):
         B.sync()
     B.close()

@@ -63,7 +63,8 @@ obs_static = eng.reset()
 a_static = torch.zeros(n, dtype=torch.int32, device=dev)
 def body():
     a_static.copy_(l3(torch.tanh(l2(torch.tanh(l1(obs_static))))).argmax(dim=1))
-    eng.step(a_static, want_final=False)                     # writes the next observations into obs_static (= eng.obs)
+    eng.step(a_static, want_final=False)                     # writes the next observations into obs_static (= eng.obs); captured, the step
+                                                             # is replay-proof: hot kernel + generic kernel, one of them a no-op
 with torch.no_grad():
     for _ in range(3):
         body()                                              # (torch wants the ops warm before a capture)
