@@ -30,7 +30,7 @@ extern "C" {
 #define PTG_ABI_VERSION 5   /* 2: + ptg_rollout_launches, ptg_rollout_info, ptg_vn_*, PTG_OBS_SB3_FLAT;  3: + ptg_profile*, ptg_step_host, ptg_host_layout, PTG_OBS_SPLIT, ptg_market_feature_series;
                              * 4: + ptg_profile_read_ex, ptg_finished_dropped, ptg_host_buffers_changed, ptg_steps_to_episode_end,
                              *    ptg_host_layout_ex (status section), ptg_step_host_begin / _tail / _end / _finish, ptg_set_feature_pitch;
-                             * 5: + ptg_note_replays (the hot kernels read the step count from the device state: captured launches can be replayed) */
+                             * 5: + ptg_note_replays, ptg_set_replay_proof (the hot kernels read the step count from the device state: captured launches can be replayed) */
 #define PTG_N_TABLES 17
 #define PTG_N_COLS 7
 #define PTG_N_INFO 24
@@ -232,10 +232,12 @@ int ptg_host_buffers_changed(ptg_env* env);
  * `stream` -- e.g. together with the policy's forward pass, whose ~10 launches per step otherwise bound a device-resident collect loop
  * (profiles/r03_policy_loop.txt) -- and the captured launches can be REPLAYED: the hot kernels read the common step count from the device
  * state.
- *   * A captured ptg_step is replay-proof: while `stream` is being captured the step is enqueued as the hot kernel, which does nothing when
- *     it finds the batch on the terminating step of the episode, plus the generic kernel behind it, which does nothing otherwise -- a
- *     replay takes the right one by itself, across episode ends, auto-reset (episode plan) and finished-episode list included, for the
- *     price of one empty launch per step.  final_obs_dev of the captured call receives the terminal observations.
+ *   * A captured ptg_step, by default, is the hot kernel alone: replay it at most ptg_steps_to_episode_end() - 1 times and make the
+ *     episode's terminating step an eager call (a replay that reaches that step raises PTG_E_INVALID at the next synchronising call).
+ *     After ptg_set_replay_proof(env, 1) a captured ptg_step is enqueued as the hot kernel, which does nothing when it finds the batch on
+ *     the terminating step, plus the generic kernel behind it, which does nothing otherwise -- a replay takes the right one by itself,
+ *     across episode ends, auto-reset (episode plan) and finished-episode list included, for the price of one empty launch per step
+ *     (+1.5-2 us).  final_obs_dev of the captured call receives the terminal observations.
  *   * A captured ptg_rollout must not be replayed across an episode end (a fused launch cannot terminate; eager calls are cut there by
  *     the host): ptg_steps_to_episode_end() says how far it may go; a replay that runs over raises PTG_E_INVALID at the next
  *     synchronising call.
@@ -245,6 +247,7 @@ int ptg_host_buffers_changed(ptg_env* env);
  * Buffers are the graph's (fixed addresses); kernel-flagged errors surface at the next ptg_sync / ptg_step_host / ptg_finished_episodes.
  * No reference counterpart. */
 int ptg_note_replays(ptg_env* env, int n_steps);
+int ptg_set_replay_proof(ptg_env* env, int enable);
 /* Number of kernel launches ptg_rollout(env, ..., n_steps, ...) would issue from the envs' current position (for
  * per-launch timing); negative PTG_E_* on a bad argument. */
 int ptg_rollout_launches(ptg_env* env, int n_steps);

@@ -59,7 +59,7 @@ STATE_FIELDS = {"meth_state": 0, "i": 1, "j": 2, "k": 3, "hot_cold": 4, "standby
 
 EXPORTS = ["ptg_abi_version", "ptg_create", "ptg_destroy", "ptg_num_envs", "ptg_obs_dim", "ptg_last_error",
            "ptg_set_market_assignment", "ptg_set_episode_plan", "ptg_set_noise_tape", "ptg_set_noise_rng", "ptg_set_global_env_offset", "ptg_set_feature_pitch", "ptg_fill_noise_tape",
-           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_host_layout_ex", "ptg_step_host_begin", "ptg_step_host_tail", "ptg_step_host_end", "ptg_step_host_finish", "ptg_host_buffers_changed", "ptg_profile", "ptg_profile_read", "ptg_profile_read_ex", "ptg_finished_dropped", "ptg_steps_to_episode_end", "ptg_note_replays", "ptg_sync", "ptg_get_state", "ptg_set_state",
+           "ptg_get_noise_tape", "ptg_reset", "ptg_step", "ptg_rollout", "ptg_rollout_info", "ptg_rollout_launches", "ptg_step_host", "ptg_host_layout", "ptg_host_layout_ex", "ptg_step_host_begin", "ptg_step_host_tail", "ptg_step_host_end", "ptg_step_host_finish", "ptg_host_buffers_changed", "ptg_profile", "ptg_profile_read", "ptg_profile_read_ex", "ptg_finished_dropped", "ptg_steps_to_episode_end", "ptg_note_replays", "ptg_set_replay_proof", "ptg_sync", "ptg_get_state", "ptg_set_state",
            "ptg_finished_episodes", "ptg_vn_init", "ptg_vn_batch_moments", "ptg_vn_apply", "ptg_vn_get", "ptg_vn_set",
            "ptg_market_feature_series", "ptg_debug_get_index_lut", "ptg_debug_window_record"]
 
@@ -156,6 +156,7 @@ def lib():
     L.ptg_finished_dropped.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ptg_steps_to_episode_end.argtypes = [vp, C.POINTER(C.c_int)]
     L.ptg_note_replays.argtypes = [vp, C.c_int]
+    L.ptg_set_replay_proof.argtypes = [vp, C.c_int]
     L.ptg_sync.argtypes = [vp, vp]
     L.ptg_get_state.argtypes = [vp, C.c_int, vp]
     L.ptg_set_state.argtypes = [vp, C.c_int, vp]

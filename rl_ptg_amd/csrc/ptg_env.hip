@@ -2054,6 +2054,7 @@ struct ptg_env {
     int* d_ladder = nullptr;
     int sync_k = -1;             // common step count k of all envs when the batch is known to be synchronised, else -1
     int step_skip_term = 0;      // argument of the next k_step_hot launch: 1 while ptg_step is being captured (see ptg_step)
+    int replay_proof = 0;        // ptg_set_replay_proof: a captured ptg_step is enqueued as hot kernel + predicated generic kernel
     // VecNormalize reward normalisation (ptg_vn_*): per-env discounted returns, running (mean, var, count), scratch
     double *vn_returns = nullptr, *vn_stats = nullptr, *vn_partials = nullptr, *vn_den = nullptr, *vn_moments = nullptr;
     size_t vn_partials_cap = 0; int vn_T_cap = 0;
@@ -2665,8 +2666,9 @@ int check_error_flags(ptg_env* h)          // after the stream has been synchron
     }
     if (__atomic_load_n(&e[2], __ATOMIC_RELAXED)) {
         __atomic_exchange_n(&e[2], 0, __ATOMIC_RELAXED);
-        return set_err(h, PTG_E_INVALID, "a hot kernel ran on the terminating step of an episode: a captured ptg_rollout was replayed past "
-                       "ptg_steps_to_episode_end (a fused launch cannot cross an episode end), or replays were not reported with ptg_note_replays");
+        return set_err(h, PTG_E_INVALID, "a hot kernel ran on the terminating step of an episode: a captured launch was replayed past "
+                       "ptg_steps_to_episode_end (ptg_set_replay_proof(env, 1) before capturing ptg_step lifts that; a fused ptg_rollout cannot cross "
+                       "an episode end), or replays were not reported with ptg_note_replays");
     }
     return 0;
 }
@@ -3148,13 +3150,15 @@ int ptg_step(ptg_env* h, const void* actions_dev, int action_kind, void* obs_dev
     hipStream_t st = as_stream(stream);
     const int k_term = h->cfg.eps_sim_steps - 6;               // the step taken at k == k_term terminates (:508-511)
     if (hot_eligible(h) && !info_dev && h->sync_k != k_term) {
-        // Being captured into a hipGraph, the step is enqueued in its replay-proof form: the hot kernel, which does nothing when it finds
-        // the batch on the terminating step, and behind it the generic kernel, which does nothing unless the batch stands there.  Every
-        // replay then takes the right one by itself -- across episode ends, auto-reset and finished-episode list included -- for the
-        // price of one empty launch per step.  (Eager calls are routed on the host as before.)
+        // Being captured into a hipGraph with ptg_set_replay_proof(env, 1), the step is enqueued in its replay-proof form: the hot kernel,
+        // which does nothing when it finds the batch on the terminating step, and behind it the generic kernel, which does nothing unless
+        // the hot kernel skipped.  Every replay then takes the right one by itself -- across episode ends, auto-reset and finished-episode
+        // list included -- for the price of one empty launch per step (+1.5-2 us; folding the generic step into the hot kernel instead cost
+        // EVERY launch 0.5 us: 4.95 -> 5.45 us, a second parameter block and scratch).  Default: the hot kernel alone, which flags a replay
+        // that reaches the terminating step.  (Eager calls are routed on the host as before.)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-        const bool capturing = cs != hipStreamCaptureStatusNone;
+        const bool capturing = cs != hipStreamCaptureStatusNone && h->replay_proof;
         h->step_skip_term = capturing ? 1 : 0;
         PTG_HOT_DISPATCH(launch_step_hot, h, st, actions_dev, action_kind, PTG_NOARG, obs_dev, rew_dev, done_dev);
         h->step_skip_term = 0;
@@ -3257,6 +3261,13 @@ int ptg_note_replays(ptg_env* h, int n_steps)
     const long long period = (long long)(h->cfg.eps_sim_steps - 6) + 1;
     h->sync_k = (int)(((long long)h->sync_k + n_steps) % period);
     h->fin_maybe = true;
+    return 0;
+}
+
+int ptg_set_replay_proof(ptg_env* h, int enable)
+{
+    if (!h) return PTG_E_INVALID;
+    h->replay_proof = enable ? 1 : 0;
     return 0;
 }
 

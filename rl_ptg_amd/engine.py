@@ -326,6 +326,11 @@ class HipEngine:
         the host-side count that routes an episode's terminating step only sees eager calls and the capture itself."""
         self._chk(self._L.ptg_note_replays(self._h, int(n_steps)))
 
+    def set_replay_proof(self, enable=True):
+        """A step() captured into a graph AFTER this call replays across episode ends by itself (hot kernel + generic kernel, one of them a
+        no-op per step: +1.5-2 us); without it a captured step must stop before the episode's terminating step (include/ptg_env.h)."""
+        self._chk(self._L.ptg_set_replay_proof(self._h, 1 if enable else 0))
+
     def sync(self):
         self._chk(self._L.ptg_sync(self._h, self._stream()))
 

@@ -89,12 +89,13 @@ def test_captured_rollout_replayed_equals_one_long_rollout():
 
 
 def test_captured_step_replays_across_episode_ends():
-    """A captured ptg_step is enqueued as the hot kernel + the generic kernel behind it (each a no-op when the step is the other's): replayed
+    """After ptg_set_replay_proof a captured ptg_step is enqueued as the hot kernel + the generic kernel behind it (each a no-op when the step is the other's): replayed
     over two and a half episodes it terminates, auto-resets over the episode plan and fills the finished-episode list exactly as eager
     calls do."""
     import torch
     n = 300
     spec, A, B = _pair(n, sim_step=3600)                    # 4-day episodes of hourly steps: 96 steps, the 91st call terminates
+    B.set_replay_proof(True)
     to_end = spec.consts["eps_sim_steps"] - 5
     R = 2 * to_end + 40
     rng = np.random.default_rng(9)
@@ -147,6 +148,27 @@ def test_captured_rollout_replayed_over_an_episode_end_is_reported():
         g.replay()
     B.sync()
     g.replay()                                              # steps 90 .. 119 would run over the terminating step (call 91)
+    with pytest.raises(RuntimeError, match="terminating step"):
+        B.sync()
+    B.close()
+
+
+def test_default_captured_step_over_the_terminating_step_is_reported():
+    """Without ptg_set_replay_proof a captured step is the hot kernel alone: all the steps it may take are fine, the terminating one is flagged."""
+    import torch
+    n = 256
+    spec, A, B = _pair(n, sim_step=3600)
+    A.close()
+    B.reset()
+    to_end = B.steps_to_episode_end()
+    assert to_end == spec.consts["eps_sim_steps"] - 5
+    act_buf = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    obs, rew, done = B.alloc_obs(1)[0], torch.zeros(n, dtype=B.out_dtype, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    g = _capture(lambda: B.step(act_buf, obs, rew, done, want_final=False))
+    for _ in range(to_end - 1):
+        g.replay()
+    B.sync()
+    g.replay()
     with pytest.raises(RuntimeError, match="terminating step"):
         B.sync()
     B.close()
